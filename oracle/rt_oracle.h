@@ -1,0 +1,119 @@
+/* TEST INFRASTRUCTURE ONLY -- a plain-C, CPU restatement of the reference renderer's hot path.
+ *
+ * Nothing in the product (raytracing_amd/, include/) includes, links or calls this library.  It is the
+ * checker used by tests/, by __graft_entry__.smoke() and by the cpu_baseline leg of bench.py.
+ *
+ * Parity status: PINNED.  Every function below is checked bit-for-bit against the reference's own code
+ * (compiled by oracle/build_ref.sh into oracle/_ref/libref.so) in tests/test_oracle_vs_ref.py, and
+ * against golden vectors generated from that build (tests/golden/, script oracle/make_golden.py).
+ *
+ * All arithmetic is IEEE binary32 with -ffp-contract=off; fused multiply-adds appear only where the
+ * reference uses FMA intrinsics (src/utility/vectorised.hpp:405-481).
+ *
+ * Array layouts are shared with oracle/ref_harness.cpp so a test can compare dumps directly.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_scene orc_scene;
+
+/* ---- stand-alone predicates --------------------------------------------------------------- */
+
+/* src/geometry.hpp:135-214.  box = {min xyz, max xyz}. */
+int orc_line_intersects_box1(const float origin[3], const float direction[3], const float box[6]);
+void orc_line_intersects_box(const float* origins, const float* directions, const float* boxes, size_t n,
+                             uint8_t* out);
+/* src/geometry.hpp:217-428.  tri = {v1 xyz, v2 xyz, v3 xyz}. */
+int orc_tri_intersects_box1(const float tri[9], const float box[6]);
+void orc_tri_intersects_box(const float* tris, const float* boxes, size_t n, uint8_t* out);
+
+/* src/utility/random.hpp:10-34: n successive unitFloatOpen() values of FastRNG{seed}. */
+void orc_fast_rng_floats(uint64_t seed, size_t n, float* out);
+
+/* ---- scene ---------------------------------------------------------------------------------- */
+
+/* Base scene -> preprocessed scene + BSP, following src/main.cpp:191-216.
+ *   tris: 3 uint32 per tri, vertex indices relative to the mesh's vertex range
+ *   meshVertexRanges / meshTriRanges: {begin,size} per base mesh
+ *   materials: 8 floats {colour[3], roughness, metalness, emission[3]}
+ *   transforms: 10 floats {position[3], quat w,x,y,z, scale[3]}
+ *   camera: 8 floats {position[3], quat w,x,y,z, fov}
+ *   inflateMode 0: root box *= 1.001 (src/main.cpp:207-208); 1: additive pad of 0.001*max extent.
+ * Returns NULL when the reference's unguarded recursion (src/bsp.hpp:276-284) would exceed depth 64. */
+orc_scene* orc_scene_create(const float* positions, const float* normals, uint32_t vertexCount,
+                            const uint32_t* tris, uint32_t triCount,
+                            const uint32_t* meshVertexRanges, const uint32_t* meshTriRanges, uint32_t meshCount,
+                            const float* materials, uint32_t materialCount,
+                            const float* transforms, const uint32_t* modelMeshes, const uint32_t* modelMaterials,
+                            uint32_t modelCount, const float* camera, uint32_t width, uint32_t height,
+                            int inflateMode);
+void orc_scene_destroy(orc_scene*);
+
+/* counts: [0] models [1] instantiated vertices [2] preprocessed tris [3] inodes [4] leaves
+ *         [5] base vertices [6] base tris [7] base meshes [8] materials */
+void orc_scene_counts(const orc_scene*, uint32_t* counts);
+
+void orc_get_preprocessed(const orc_scene*, float* positions, float* normals, uint32_t* vertexRanges,
+                          float* pretris, uint32_t* triRanges, float* modelMaterials, float* cameraPosition,
+                          float* pixelToRay, float* rootBox);
+void orc_get_bsp(const orc_scene*, float* rootBox, int32_t* rootIndex, float* inodeBoxes, int32_t* inodeInts,
+                 uint32_t* leafCounts, uint32_t* leafRefs);
+
+/* src/bsp.hpp:50-145.  outFloats: t,u,v,point[3]; outIds: mesh,tri (0xFFFFFFFF on a miss). */
+void orc_intersect(const orc_scene*, const float* origins, const float* directions, size_t n, float tMin,
+                   int frontOnly, float* outFloats, uint32_t* outIds);
+/* src/render.hpp:227 */
+void orc_camera_rays(const orc_scene*, const float* sampleXY, size_t n, float* directions);
+
+/* ---- reference-mode shading (FastRNG + libm sinf/cosf), bit-comparable with the reference ---- */
+
+/* src/render.hpp:53-212 with FastRNG{seeds[i]} per ray. */
+void orc_ray_trace(const orc_scene*, const float* origins, const float* directions, const uint64_t* seeds, size_t n,
+                   float* out);
+/* src/render.hpp:219-232 with a runtime sample count; pixel p uses FastRNG{seed + p}. */
+void orc_render(const orc_scene*, uint32_t spp, uint64_t seed, float* image);
+
+/* ---- device-mode rendering: same estimator, counter-based RNG, polynomial sincos ------------- */
+
+typedef struct {
+    uint32_t width, height;          /* full image size (defines the pixel index y*width+x) */
+    uint32_t x0, y0, w, h;           /* rectangle rendered into `image` (row-major w*h*3) */
+    uint32_t spp;
+    uint32_t bounceLimit;            /* src/render.hpp:49 (8 there; any value here) */
+    float tMin;                      /* src/render.hpp:48 */
+    uint64_t seed;
+    float cameraPosition[3];
+    float pixelToRay[9];             /* column-major, src/camera.hpp:45 */
+} orc_render_params;
+
+typedef struct {
+    uint64_t segments;               /* closest-hit queries issued by the path loop (src/render.hpp:104) */
+    uint64_t shadedHits;             /* hits that sampled a continuation direction */
+    uint64_t boxTests;               /* calls of the box test (src/bsp.hpp:107) */
+    uint64_t trisTested;             /* real triangles run through the ray/tri test */
+    uint64_t leafVisits;
+    uint64_t inodeVisits;
+    uint64_t paths;
+} orc_stats;
+
+void orc_render_device_mode(const orc_scene*, const orc_render_params*, float* image, orc_stats* stats, int threads);
+
+/* Building blocks of device mode, exposed so tests can pin them individually. */
+void orc_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+float orc_u32_to_unit_float(uint32_t v);
+void orc_sincos_2pi(float u, float* s, float* c);
+/* Radiance of one path: pixel index, sample index; writes rgb. */
+void orc_path_radiance_device_mode(const orc_scene*, const orc_render_params*, uint32_t pixelX, uint32_t pixelY,
+                                   uint32_t sample, float rgb[3], orc_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
