@@ -1,0 +1,147 @@
+/* rt_amd.h -- C ABI of the MI355X path-tracing core (librt_amd.so).
+ *
+ * This is the drop-in boundary for the reference renderer's hot path.  The reference has no plugin
+ * ABI of its own: its hot path sits behind the inline C++ function
+ *     void render(RenderData const& data, Span<glm::vec3> image)         src/render.hpp:215
+ * whose only caller is src/main.cpp:230, and behind
+ *     BSPTree::lineTriNearestIntersection<Surfaces>(Line const&, float)  src/bsp.hpp:50-51
+ * Every entry point below names the reference interface it stands in for.  Plain pointers and
+ * sizes only; no C++ or torch types cross this boundary.  All functions return 0 on success and a
+ * negative rt_status otherwise; rt_last_error() gives the message for the calling thread.
+ *
+ * Threading: a scene handle may be used by one host thread at a time; use one handle per GPU.
+ * All "device" pointers are HIP device pointers on the scene's GPU.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument / inconsistent description */
+    RT_ERR_HIP = -2,          /* a HIP runtime call failed */
+    RT_ERR_NO_DEVICE = -3,    /* no usable GPU */
+    RT_ERR_LIMIT = -4,        /* tree deeper than the traversal stack, size overflow */
+    RT_ERR_NOMEM = -5
+} rt_status;
+
+/* One interior node exactly as the reference stores it (BSPTree::INode, src/bsp.hpp:148-159):
+ * two child Nodes {box min xyz, box max xyz, index} and the division axis.  60 bytes.
+ * index > 0: interior node (index-1);  index < 0: leaf (-index-1);  index == 0: empty. */
+typedef struct {
+    float neg_box[6]; int32_t neg_index;
+    float pos_box[6]; int32_t pos_index;
+    uint8_t axis; uint8_t pad_[3];
+} rt_inode;
+
+/* {model (mesh instance) index, triangle index within the model}: MeshTriIndex, src/mesh.hpp:50-53,
+ * widened from 16 to 32 bits. */
+typedef struct { uint32_t mesh, tri; } rt_tri_ref;
+
+/* Scene description = BSPTree contents (src/bsp.hpp:170-172) + RayTraceData (src/render.hpp:28-35)
+ * with the model->mesh and model->material permutations already applied.  The caller keeps
+ * ownership; rt_scene_create copies what it needs into HBM. */
+typedef struct {
+    /* BSPTree::_root, _inodes, _leaves */
+    float root_box[6];
+    int32_t root_index;
+    const rt_inode* inodes;
+    uint32_t inode_count;
+    const uint32_t* leaf_first_ref;      /* leaf_count+1 offsets into leaf_refs (leaf order preserved) */
+    const rt_tri_ref* leaf_refs;         /* Leaf::triIndices of every leaf, concatenated */
+    uint32_t leaf_count;
+    /* Scene::preprocessedTris (src/mesh.hpp:141-144): 12 floats {normal, v1, v1ToV3, v1ToV2} */
+    const float* pretris;
+    const uint32_t* model_pretri_begin;  /* model_count+1 offsets: model m owns [begin[m], begin[m+1]) */
+    uint32_t pretri_count;
+    /* RayTraceData::vertexNormals / vertexRanges (instantiated meshes) */
+    const float* vertex_normals;
+    const uint32_t* model_vertex_begin;  /* model_count+1 offsets into vertex_normals */
+    uint32_t vertex_count;
+    /* RayTraceData::tris / triRanges (base meshes; indices relative to the mesh's vertex range) */
+    const uint32_t* base_tris;           /* 3 per triangle */
+    const uint32_t* model_tri_begin;     /* per model: first base triangle of its mesh */
+    uint32_t base_tri_count;
+    /* RayTraceData::materials: PreprocessedMaterial per model (src/material.hpp:23-29), 12 floats
+     * {ndfAlphaSq, geometryAlphaSq, f0[3], adjustedColour[3], emission[3], 0} */
+    const float* model_materials;
+    uint32_t model_count;
+} rt_scene_desc;
+
+typedef struct rt_scene rt_scene;
+
+/* LineMeshIntersection (src/bsp.hpp:23-29).  mesh == 0xFFFFFFFF marks "no intersection"
+ * (std::nullopt in the reference). */
+typedef struct {
+    float t, u, v;            /* t, pointCoord2, pointCoord3 */
+    float point[3];
+    uint32_t mesh, tri;
+} rt_hit;
+
+#define RT_FLAG_COUNT_WORK      1u   /* fill the work counters of rt_stats (slower kernels) */
+#define RT_FLAG_PROFILE_KERNELS 2u   /* time every kernel launch with HIP events (adds syncs at the end) */
+
+/* RenderData (src/render.hpp:38-44) + the compile-time constants of src/render.hpp:47-49 made
+ * run-time, + a tile rectangle for multi-GPU sharding. */
+typedef struct {
+    uint32_t width, height;       /* full image; defines the pixel index y*width+x used by the RNG */
+    uint32_t x0, y0, w, h;        /* rectangle to render; output is row-major w*h*3 floats */
+    uint32_t spp;                 /* PIXEL_SAMPLE_RATE */
+    uint32_t bounce_limit;        /* RAY_BOUNCE_LIMIT */
+    float t_min;                  /* RAY_INTERSECTION_T_MIN */
+    uint64_t seed;
+    float camera_position[3];
+    float pixel_to_ray[9];        /* column-major mat3 {right, down, o}, src/camera.hpp:45 */
+    uint32_t flags;
+    uint32_t max_batch_paths;     /* 0 = default */
+} rt_render_params;
+
+typedef struct {
+    uint64_t paths;
+    uint64_t segments;            /* closest-hit queries issued by the path loop, src/render.hpp:104 */
+    uint64_t shaded_hits;
+    uint64_t box_tests, tris_tested, leaf_visits, inode_visits;   /* RT_FLAG_COUNT_WORK only */
+    double ms_total;              /* whole call, host clock, after the final sync */
+    double ms_raygen, ms_trace, ms_shade, ms_accumulate;          /* RT_FLAG_PROFILE_KERNELS only */
+    uint32_t trace_launches, batches;
+} rt_stats;
+
+/* Upload a scene to GPU `device` (replaces constructing RayTraceData, src/main.cpp:219-229). */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+/* Bytes of HBM held by the scene, and the depth of its tree. */
+int rt_scene_info(const rt_scene* scene, uint64_t* device_bytes, uint32_t* node_count, uint32_t* leaf_tri_count,
+                  uint32_t* depth);
+
+/* BSPTree::lineTriNearestIntersection<Surfaces> (src/bsp.hpp:50-145) for n lines.
+ * origins/directions: 3 floats per line.  Host-pointer and device-pointer forms. */
+int rt_intersect(rt_scene* scene, const float* origins, const float* directions, uint64_t n, float t_min,
+                 int front_only, rt_hit* out);
+int rt_intersect_device(rt_scene* scene, const float* d_origins, const float* d_directions, uint64_t n,
+                        float t_min, int front_only, rt_hit* d_out, void* hip_stream);
+
+/* render() (src/render.hpp:215-234): mean radiance per pixel, linear HDR, row-major, 3 floats per
+ * pixel.  rt_render writes to host memory, rt_render_device to device memory (no PCIe copy). */
+int rt_render(rt_scene* scene, const rt_render_params* params, float* out_rgb, rt_stats* stats);
+int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_out_rgb, rt_stats* stats,
+                     void* hip_stream);
+
+/* Test hook: evaluates one scalar building block of the kernels on the GPU for n inputs so that its
+ * bits can be pinned: op 0 a/b, 1 sqrt(a), 2 sin,cos(2*pi*a) (2 outputs), 3 Philox words (2 outputs),
+ * 4 fma(a,b,a), 5 a*b+a unfused.  Not part of the rendering interface. */
+int rt_selftest_math(int op, const float* a, const float* b, uint32_t n, float* out);
+
+const char* rt_last_error(void);
+/* Library/ABI version, bumped on any layout change of the structs above. */
+uint32_t rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,909 @@
+// MI355X (gfx950) wavefront path tracer behind the C ABI of include/rt_amd.h.
+//
+// Numerics contract: every floating-point operation on the path from a ray to a hit record and from
+// a hit record to radiance is IEEE binary32, evaluated in the same order and with the same fused
+// multiply-adds as the reference (src/geometry.hpp:99-214, src/bsp.hpp:58-141, src/render.hpp:53-212,
+// src/utility/vectorised.hpp:405-481).  This file must be compiled with -ffp-contract=off; fused
+// operations are written explicitly with __fmaf_rn.  Division and square root use HIP's default
+// correctly rounded forms.
+#include "rt_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define RT_STACK_MAX 64          // per-lane traversal stack entries (tree depth bound)
+#define RT_BLOCK 256
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg) {
+    g_lastError = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Device data layout
+// ------------------------------------------------------------------------------------------------
+// Node record, 32 bytes = two float4:  q0 = {lo.x, lo.y, lo.z, hi.x}  q1 = {hi.y, hi.z, index, aux}
+//   index > 0 : interior; children are nodes[index] (negative side) and nodes[index+1] (positive);
+//               aux = division axis.  The split plane is the centre of the node's own box on that
+//               axis, which is how BSPTree computes positiveChild.box.min[axis] (src/bsp.hpp:256-274).
+//   index < 0 : leaf; triangles are leafTris[-index-1 .. -index-1+aux)
+//   index == 0: empty
+// Leaf triangle record, 64 bytes = four float4, stored once per (leaf, triangle) reference so a leaf's
+// triangles are contiguous:  {n.x n.y n.z v1.x} {v1.y v1.z e13.x e13.y} {e13.z e12.x e12.y e12.z}
+// {mesh, tri, gtri, 0} with gtri the scene-wide index of the instantiated triangle.
+// Triangle normals, 48 bytes per gtri: the three instantiated vertex normals, padded to 3 float4.
+// Material, 48 bytes per model: {ndfAlphaSq geomAlphaSq f0.x f0.y} {f0.z adj.x adj.y adj.z} {em.x em.y em.z 0}.
+struct DevScene {
+    const float4* nodes;
+    const float4* leafTris;
+    const float4* triNormals;
+    const float4* materials;
+};
+
+struct Counters {
+    unsigned long long boxTests, trisTested, leafVisits, inodeVisits, shadedHits, segments, paths;
+};
+
+struct RenderConst {
+    float camPos[3];
+    float m[9];
+    uint32_t width;
+    uint32_t x0, y0, w, h;
+    uint32_t bounceLimit;
+    float tMin;
+    uint32_t key0, key1;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Device math
+// ------------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// Unfused sum of products, left to right (glm scalar dot).
+__device__ __forceinline__ float dotU(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 crossU(V3 a, V3 b) {
+    return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ V3 normalizeU(V3 a) { return a * (1.0f / sqrtf(dotU(a, a))); }
+// Fused forms of the reference's AVX wrappers (src/utility/vectorised.hpp:466-481).
+__device__ __forceinline__ float dotF(V3 a, V3 b) { return __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 crossF(V3 a, V3 b) {
+    return mk(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x)));
+}
+
+// One face of the reference's six-face box test (src/geometry.hpp:136-212).
+__device__ __forceinline__ bool faceHit(float denom, float numer, float oa, float da, float loa, float hia, float ob,
+                                        float db, float lob, float hib) {
+    if (fabsf(denom) < 1e-6f) return false;
+    float const t = numer / denom;
+    if (!(t >= 0.0f)) return false;
+    float const pa = oa + t * da;
+    if (!(pa >= loa && pa <= hia)) return false;
+    float const pb = ob + t * db;
+    return pb >= lob && pb <= hib;
+}
+
+__device__ __forceinline__ bool lineBox(V3 o, V3 d, V3 lo, V3 hi) {
+    return faceHit(-d.x, o.x - lo.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z)
+        || faceHit(d.x, hi.x - o.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z)
+        || faceHit(-d.y, o.y - lo.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z)
+        || faceHit(d.y, hi.y - o.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z)
+        || faceHit(-d.z, o.z - lo.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y)
+        || faceHit(d.z, hi.z - o.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y);
+}
+
+struct HitRec {
+    float t, u, v;
+    uint32_t ref;       // index of the leaf triangle record, 0xFFFFFFFF = miss
+};
+
+// Nearest intersection, src/bsp.hpp:50-145, with the recursion unrolled onto a per-lane stack of
+// deferred far children.  Visiting order, the per-node box test, the first-leaf-with-a-hit
+// termination and the in-leaf-box acceptance test are those of the reference.
+template <bool FRONT_ONLY, bool COUNT>
+__device__ __forceinline__ HitRec closestHit(const DevScene& S, V3 o, V3 d, float tMin, Counters& c) {
+    uint32_t stack[RT_STACK_MAX];
+    int sp = 0;
+    uint32_t cur = 0;
+    HitRec best;
+    best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = 0xFFFFFFFFu;
+    for (;;) {
+        float4 const q0 = S.nodes[2 * cur];
+        float4 const q1 = S.nodes[2 * cur + 1];
+        V3 const lo = mk(q0.x, q0.y, q0.z), hi = mk(q0.w, q1.x, q1.y);
+        if (COUNT) c.boxTests++;
+        if (lineBox(o, d, lo, hi)) {
+            int const index = __float_as_int(q1.z);
+            uint32_t const aux = __float_as_uint(q1.w);
+            if (index > 0) {
+                if (COUNT) c.inodeVisits++;
+                float const la = aux == 0 ? lo.x : (aux == 1 ? lo.y : lo.z);
+                float const ha = aux == 0 ? hi.x : (aux == 1 ? hi.y : hi.z);
+                float const oa = aux == 0 ? o.x : (aux == 1 ? o.y : o.z);
+                float const plane = (la + ha) / 2.0f;
+                bool const positiveNear = (oa - plane) >= 0.0f;            // src/bsp.hpp:133
+                uint32_t const base = static_cast<uint32_t>(index);
+                stack[sp++] = positiveNear ? base : base + 1;               // far child
+                cur = positiveNear ? base + 1 : base;                       // near child
+                continue;
+            }
+            if (index < 0) {
+                if (COUNT) { c.leafVisits++; c.trisTested += aux; }
+                uint32_t const first = static_cast<uint32_t>(-(index + 1));
+                bool has = false;
+                for (uint32_t j = 0; j < aux; ++j) {
+                    float4 const* tp = S.leafTris + 4 * static_cast<size_t>(first + j);
+                    float4 const a = tp[0], b = tp[1], e = tp[2];
+                    V3 const n = mk(a.x, a.y, a.z), v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x),
+                             e12 = mk(e.y, e.z, e.w);
+                    // lineTrisIntersection, src/geometry.hpp:117-132 (one lane of the 8-wide form).
+                    float const negDet = dotF(n, d);
+                    bool const detOk = FRONT_ONLY ? (negDet <= -1e-6f) : (fabsf(negDet) >= 1e-6f);
+                    if (!detOk) continue;
+                    float const invDet = -1.0f / negDet;
+                    V3 const AO = o - v1;
+                    float const t = dotF(AO, n) * invDet;
+                    V3 const DAO = crossF(AO, d);
+                    float const u = dotF(e13, DAO) * invDet;
+                    float const v = (0.0f - dotF(e12, DAO)) * invDet;
+                    if (!(u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f)) continue;
+                    if (!(t < best.t && t >= tMin)) continue;                // src/bsp.hpp:79
+                    V3 const p = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+                    bool const inBox = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z
+                                    && p.z <= hi.z;
+                    if (inBox) { best.t = t; best.u = u; best.v = v; best.ref = first + j; has = true; }
+                }
+                if (has) break;                                             // src/bsp.hpp:136-138
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return best;
+}
+
+// Philox-4x32-10 keyed by the render seed; counter = (pixel index, sample index, dimension pair, 0).
+__device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1, uint32_t& r0,
+                                       uint32_t& r1) {
+    uint32_t c3 = 0;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t const h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t const h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t const n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r0 = c0; r1 = c1;
+}
+__device__ __forceinline__ float unitFloat(uint32_t v) { return static_cast<float>(v >> 8) * 0x1p-24f; }
+
+// sin and cos of 2*pi*u, u in [0,1): exact quadrant reduction, then fixed polynomials on
+// [-pi/4, pi/4] evaluated with explicit fused multiply-adds (bit-reproducible on any IEEE machine).
+__device__ __forceinline__ void sincos2pi(float u, float& s, float& c) {
+    float const x = u * 4.0f;
+    float const k = rintf(x);
+    float const r = x - k;
+    float const a = r * 1.57079632679489661923f;
+    float const a2 = a * a;
+    float const sn = __fmaf_rn(a * a2, __fmaf_rn(a2, __fmaf_rn(a2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), a);
+    float const cp = __fmaf_rn(a2, __fmaf_rn(a2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+    float const cn = __fmaf_rn(a2 * a2, cp, __fmaf_rn(a2, -0.5f, 1.0f));
+    int const q = static_cast<int>(k) & 3;
+    float ss = (q & 1) ? cn : sn;
+    float cc = (q & 1) ? sn : cn;
+    if (q == 1) cc = -cc;
+    else if (q == 2) { ss = -ss; cc = -cc; }
+    else if (q == 3) ss = -ss;
+    s = ss; c = cc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernels
+// ------------------------------------------------------------------------------------------------
+
+// Wave-aggregated counter flush: one atomic per wave and counter.
+__device__ __forceinline__ unsigned long long waveSum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void flushCounters(const Counters& c, Counters* g) {
+    unsigned long long const b = waveSum(c.boxTests), t = waveSum(c.trisTested), l = waveSum(c.leafVisits),
+                             i = waveSum(c.inodeVisits);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g->boxTests, b);
+        atomicAdd(&g->trisTested, t);
+        atomicAdd(&g->leafVisits, l);
+        atomicAdd(&g->inodeVisits, i);
+    }
+}
+
+// rt_intersect: one lane per line.
+template <bool FRONT_ONLY>
+__global__ __launch_bounds__(RT_BLOCK) void k_intersect(DevScene S, const float* __restrict__ origins,
+                                                        const float* __restrict__ directions, uint64_t n,
+                                                        float tMin, rt_hit* __restrict__ out) {
+    uint64_t const stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    Counters c = {};
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        V3 const o = mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+        V3 const d = mk(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]);
+        HitRec const h = closestHit<FRONT_ONLY, false>(S, o, d, tMin, c);
+        rt_hit r;
+        if (h.ref != 0xFFFFFFFFu) {
+            float4 const ids = S.leafTris[4 * static_cast<size_t>(h.ref) + 3];
+            r.t = h.t; r.u = h.u; r.v = h.v;
+            r.point[0] = o.x + h.t * d.x; r.point[1] = o.y + h.t * d.y; r.point[2] = o.z + h.t * d.z;
+            r.mesh = __float_as_uint(ids.x); r.tri = __float_as_uint(ids.y);
+        }
+        else {
+            r.t = 0.0f; r.u = 0.0f; r.v = 0.0f;
+            r.point[0] = r.point[1] = r.point[2] = 0.0f;
+            r.mesh = 0xFFFFFFFFu; r.tri = 0xFFFFFFFFu;
+        }
+        out[i] = r;
+    }
+}
+
+// Path state, structure of arrays over the batch's path slots (slot = sampleInBatch * pixels + pixel):
+//   A = {origin.xyz, dir.x}   B = {dir.y, dir.z, throughput.x, throughput.y}
+//   C = {throughput.z, radiance.xyz}
+struct PathState {
+    float4* A;
+    float4* B;
+    float4* C;
+    float4* hit;          // {t, u, v, ref}
+    uint32_t* queue[2];   // path slots still alive, ping-pong
+    uint32_t* counts;     // counts[b] = number of paths entering bounce b
+};
+
+// Camera rays, src/render.hpp:225-228: jittered sample position, direction = normalize(M * (sx, sy, 1)).
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P, uint32_t pixels, uint32_t sampleBase,
+                                                     uint32_t paths) {
+    uint32_t const stride = gridDim.x * blockDim.x;
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < paths; id += stride) {
+        uint32_t const sLocal = id / pixels, p = id - sLocal * pixels;
+        uint32_t const px = R.x0 + p % R.w, py = R.y0 + p / R.w;
+        uint32_t r0, r1;
+        philox(py * R.width + px, sampleBase + sLocal, 0u, R.key0, R.key1, r0, r1);
+        float const sx = static_cast<float>(px) + unitFloat(r0);
+        float const sy = static_cast<float>(py) + unitFloat(r1);
+        V3 const v = mk(R.m[0] * sx + R.m[3] * sy + R.m[6] * 1.0f, R.m[1] * sx + R.m[4] * sy + R.m[7] * 1.0f,
+                        R.m[2] * sx + R.m[5] * sy + R.m[8] * 1.0f);
+        V3 const d = normalizeU(v);
+        P.A[id] = make_float4(R.camPos[0], R.camPos[1], R.camPos[2], d.x);
+        P.B[id] = make_float4(d.y, d.z, 1.0f, 1.0f);
+        P.C[id] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.counts[0] = paths;
+}
+
+// One closest-hit query per live path.  `bounce` selects the input queue; bounce 0 is the identity.
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, PathState P, uint32_t bounce, float tMin,
+                                                    Counters* __restrict__ gc) {
+    uint32_t const n = P.counts[bounce];
+    uint32_t const* __restrict__ q = P.queue[bounce & 1];
+    uint32_t const stride = gridDim.x * blockDim.x;
+    Counters c = {};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t const slot = bounce == 0 ? i : q[i];
+        float4 const A = P.A[slot], B = P.B[slot];
+        HitRec const h = closestHit<true, COUNT>(S, mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), tMin, c);
+        P.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.ref));
+    }
+    if (COUNT) flushCounters(c, gc);
+}
+
+// Per-bounce shading: emission pick-up, GGX half-vector sampling, Cook-Torrance weight
+// (src/render.hpp:106-175 and the per-lane arithmetic of :58-83, :186-207 applied incrementally),
+// then compaction of the surviving paths into the next queue with one atomic per wave.
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, PathState P, uint32_t bounce,
+                                                    uint32_t sampleBase, uint32_t pixels,
+                                                    Counters* __restrict__ gc) {
+    uint32_t const n = P.counts[bounce];
+    uint32_t const* __restrict__ qin = P.queue[bounce & 1];
+    uint32_t* __restrict__ qout = P.queue[(bounce + 1) & 1];
+    uint32_t const lane = threadIdx.x & 63;
+    uint32_t const stride = gridDim.x * blockDim.x;
+    uint32_t shaded = 0;
+    // The loop bound is wave-uniform so that every lane reaches the ballot.
+    uint32_t const first = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+    for (uint32_t base = first; base < n; base += stride) {
+        uint32_t const i = base + lane;
+        bool alive = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = bounce == 0 ? i : qin[i];
+            float4 const H = P.hit[slot];
+            uint32_t const ref = __float_as_uint(H.w);
+            if (ref != 0xFFFFFFFFu) {
+                float4 const A = P.A[slot], B = P.B[slot];
+                float4 C = P.C[slot];
+                V3 const o = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
+                V3 T = mk(B.z, B.w, C.x), L = mk(C.y, C.z, C.w);
+                float4 const ids = S.leafTris[4 * static_cast<size_t>(ref) + 3];
+                uint32_t const mesh = __float_as_uint(ids.x), gtri = __float_as_uint(ids.z);
+                float4 const m0 = S.materials[3 * mesh], m1 = S.materials[3 * mesh + 1], m2 = S.materials[3 * mesh + 2];
+                float const ndfA = m0.x, geoA = m0.y;
+                V3 const f0 = mk(m0.z, m0.w, m1.x), adj = mk(m1.y, m1.z, m1.w), em = mk(m2.x, m2.y, m2.z);
+                // outgoingLight = fma(lightWeight, emission, outgoingLight), src/render.hpp:206
+                L = mk(__fmaf_rn(T.x, em.x, L.x), __fmaf_rn(T.y, em.y, L.y), __fmaf_rn(T.z, em.z, L.z));
+                if (bounce < R.bounceLimit) {                                    // src/render.hpp:117
+                    ++shaded;
+                    float4 const n0 = S.triNormals[3 * static_cast<size_t>(gtri)],
+                                 n1 = S.triNormals[3 * static_cast<size_t>(gtri) + 1],
+                                 n2 = S.triNormals[3 * static_cast<size_t>(gtri) + 2];
+                    V3 const vn1 = mk(n0.x, n0.y, n0.z), vn2 = mk(n0.w, n1.x, n1.y), vn3 = mk(n1.z, n1.w, n2.x);
+                    float const c2 = H.y, c3 = H.z;
+                    float const c1 = 1.0f - c2 - c3;
+                    V3 normal = vn1 * c1 + vn2 * c2 + vn3 * c3;                  // src/render.hpp:128-129
+                    V3 const outgoing = neg(d);
+                    float nDotO = dotU(normal, outgoing);
+                    if (nDotO < 0.0f) { nDotO = -nDotO; normal = neg(normal); }
+                    // orthonormalBasis, src/utility/math.hpp:38-54
+                    V3 ref2 = mk(0.56863665f, -0.77215318f, 0.28360506f);
+                    float dp = dotU(normal, ref2);
+                    if (fabsf(1.0f - fabsf(dp)) < 1e-3f) {
+                        ref2 = mk(0.56863665f, 0.77215318f, 0.28360506f);
+                        dp = dotU(normal, ref2);
+                    }
+                    V3 const p1 = normalizeU(ref2 - normal * dp);
+                    V3 const p2 = crossU(normal, p1);
+                    // GGX sampling of the half vector, src/render.hpp:145-153
+                    uint32_t const sLocal = slot / pixels, p = slot - sLocal * pixels;
+                    uint32_t const px = R.x0 + p % R.w, py = R.y0 + p / R.w;
+                    uint32_t r0, r1;
+                    philox(py * R.width + px, sampleBase + sLocal, bounce + 1u, R.key0, R.key1, r0, r1);
+                    float const thetaParam = unitFloat(r0);
+                    float const cosThetaSq = 1.0f / (1.0f + ndfA * thetaParam / (1.0f - thetaParam));
+                    float const cosTheta = sqrtf(cosThetaSq);
+                    float const sinTheta = sqrtf(1.0f - cosThetaSq);
+                    float sinPhi, cosPhi;
+                    sincos2pi(unitFloat(r1), sinPhi, cosPhi);
+                    V3 const tangent = p1 * cosPhi + p2 * sinPhi;
+                    V3 const halfway = normal * cosTheta + tangent * sinTheta;
+                    float const hDotO = dotU(halfway, outgoing);
+                    V3 const incident = halfway * (2.0f * hDotO) - outgoing;
+                    float const nDotI = dotU(normal, incident);
+                    if (nDotI > 0.0f) {                                          // src/render.hpp:169
+                        // Fresnel-Schlick, src/render.hpp:77-83
+                        float const omh = 1.0f - hDotO;
+                        float const pw = ((((1.0f * omh) * omh) * omh) * omh) * omh;
+                        V3 const F = mk(__fmaf_rn(-f0.x, pw, f0.x + pw), __fmaf_rn(-f0.y, pw, f0.y + pw),
+                                        __fmaf_rn(-f0.z, pw, f0.z + pw));
+                        // GGX distribution, src/render.hpp:58-63 (nDotH is the sampled cosTheta, :166)
+                        float const pi = 3.14159265358979323846264338327950288f;
+                        float const nDotHSq = cosTheta * cosTheta;
+                        float const tanSq = 1.0f / nDotHSq - 1.0f;
+                        float const aPlus = ndfA + tanSq;
+                        float const D = ndfA / (pi * (nDotHSq * nDotHSq) * (aPlus * aPlus));
+                        // Smith-GGX geometry, src/render.hpp:66-74
+                        float const gI = 1.0f + sqrtf(1.0f + geoA / (nDotI * nDotI) - geoA);
+                        float const gO = 1.0f + sqrtf(1.0f + geoA / (nDotO * nDotO) - geoA);
+                        float const G = 4.0f / (gI * gO);
+                        // src/render.hpp:191-193
+                        float const dScale = 4.0f * nDotI * hDotO / (D * cosTheta);
+                        float const sScale = G * hDotO / (nDotO * cosTheta);
+                        V3 const diffuse = mk(__fmaf_rn(-F.x, adj.x, adj.x) * dScale, __fmaf_rn(-F.y, adj.y, adj.y) * dScale,
+                                              __fmaf_rn(-F.z, adj.z, adj.z) * dScale);
+                        V3 const spec = nDotO > 0.0f ? mk(F.x * sScale, F.y * sScale, F.z * sScale) : mk(0.0f, 0.0f, 0.0f);
+                        V3 const w = diffuse + spec;
+                        T = mk(w.x * T.x, w.y * T.y, w.z * T.z);                 // src/render.hpp:200-202
+                        V3 const point = mk(o.x + H.x * d.x, o.y + H.x * d.y, o.z + H.x * d.z);
+                        P.A[slot] = make_float4(point.x, point.y, point.z, incident.x);
+                        P.B[slot] = make_float4(incident.y, incident.z, T.x, T.y);
+                        alive = true;
+                    }
+                }
+                C = make_float4(T.z, L.x, L.y, L.z);
+                P.C[slot] = C;
+            }
+        }
+        // Stream compaction: ballot, prefix count below the lane, one atomic per wave.
+        unsigned long long const mask = __ballot(alive);
+        if (mask != 0ull) {
+            uint32_t const cnt = static_cast<uint32_t>(__popcll(mask));
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(&P.counts[bounce + 1], cnt);
+            start = __shfl(start, 0, 64);
+            if (alive) {
+                uint32_t const rank = static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+                qout[start + rank] = slot;
+            }
+        }
+    }
+    unsigned long long const s = waveSum(shaded);
+    if (lane == 0 && s) atomicAdd(&gc->shadedHits, s);
+}
+
+// Adds the batch's radiance to the per-pixel accumulator in sample order (the order of the
+// reference's `colour += rayTrace(...)` loop, src/render.hpp:224-230), and on the last batch divides
+// by the sample count (src/render.hpp:231) and writes the image.
+__global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathState P, float* __restrict__ accum, uint32_t pixels,
+                                                         uint32_t samplesInBatch, uint32_t bounceCount, int last,
+                                                         float sppF, float* __restrict__ out,
+                                                         Counters* __restrict__ gc) {
+    uint32_t const p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < pixels) {
+        float r = accum[3 * static_cast<size_t>(p)], g = accum[3 * static_cast<size_t>(p) + 1],
+              b = accum[3 * static_cast<size_t>(p) + 2];
+        for (uint32_t s = 0; s < samplesInBatch; ++s) {
+            float4 const C = P.C[static_cast<size_t>(s) * pixels + p];
+            r = r + C.y; g = g + C.z; b = b + C.w;
+        }
+        if (last) {
+            out[3 * static_cast<size_t>(p)] = r / sppF;
+            out[3 * static_cast<size_t>(p) + 1] = g / sppF;
+            out[3 * static_cast<size_t>(p) + 2] = b / sppF;
+        }
+        else {
+            accum[3 * static_cast<size_t>(p)] = r;
+            accum[3 * static_cast<size_t>(p) + 1] = g;
+            accum[3 * static_cast<size_t>(p) + 2] = b;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long seg = 0;
+        for (uint32_t k = 0; k < bounceCount; ++k) seg += P.counts[k];
+        gc->segments += seg;
+        gc->paths += P.counts[0];
+    }
+}
+
+// Device-side evaluation of the scalar building blocks, so tests can pin their bits.
+__global__ void k_selftest(int op, const float* __restrict__ a, const float* __restrict__ b, uint32_t n,
+                           float* __restrict__ out) {
+    uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (op) {
+    case 0: out[i] = a[i] / b[i]; break;
+    case 1: out[i] = sqrtf(a[i]); break;
+    case 2: { float s, c; sincos2pi(a[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break; }
+    case 3: {
+        uint32_t r0, r1;
+        philox(__float_as_uint(a[i]), __float_as_uint(b[i]), 7u, 0x5EEDu, 0x1234u, r0, r1);
+        out[2 * i] = __uint_as_float(r0); out[2 * i + 1] = __uint_as_float(r1);
+        break;
+    }
+    case 4: out[i] = __fmaf_rn(a[i], b[i], a[i]); break;
+    case 5: out[i] = a[i] * b[i] + a[i]; break;          // must NOT be fused
+    default: out[i] = 0.0f;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Host side of the C ABI
+// ------------------------------------------------------------------------------------------------
+
+struct rt_scene {
+    int device = 0;
+    DevScene dev{};
+    void* dNodes = nullptr;
+    void* dLeafTris = nullptr;
+    void* dTriNormals = nullptr;
+    void* dMaterials = nullptr;
+    uint64_t deviceBytes = 0;
+    uint32_t nodeCount = 0, leafTriCount = 0, depth = 0, modelCount = 0;
+    int cuCount = 256;
+    // render workspace, grown on demand
+    uint64_t wsPaths = 0, wsPixels = 0;
+    void* wsA = nullptr; void* wsB = nullptr; void* wsC = nullptr; void* wsHit = nullptr;
+    void* wsQ0 = nullptr; void* wsQ1 = nullptr; void* wsCounts = nullptr; void* wsAccum = nullptr;
+    void* wsCounters = nullptr;
+    void* wsOut = nullptr; uint64_t wsOutPixels = 0;
+};
+
+namespace {
+
+void freeWorkspace(rt_scene* s) {
+    for (void** p : {&s->wsA, &s->wsB, &s->wsC, &s->wsHit, &s->wsQ0, &s->wsQ1, &s->wsAccum}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    s->wsPaths = 0;
+    s->wsPixels = 0;
+}
+
+int gridFor(const rt_scene* s, uint64_t items) {
+    uint64_t const blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
+    uint64_t const cap = static_cast<uint64_t>(s->cuCount) * 8;     // 8 blocks of 256 per CU = 32 waves/CU
+    return static_cast<int>(std::max<uint64_t>(1, std::min(blocks, cap)));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_lastError.c_str(); }
+uint32_t rt_abi_version(void) { return 1; }
+
+int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
+    if (!D || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
+    if (!D->model_pretri_begin || !D->model_vertex_begin || !D->model_tri_begin || !D->model_materials || !D->pretris
+        || !D->vertex_normals || !D->base_tris || !D->leaf_first_ref)
+        return fail(RT_ERR_INVALID, "rt_scene_create: null array in description");
+    if (D->inode_count && !D->inodes) return fail(RT_ERR_INVALID, "rt_scene_create: inodes missing");
+    uint32_t const refCount = D->leaf_first_ref[D->leaf_count];
+    if (refCount && !D->leaf_refs) return fail(RT_ERR_INVALID, "rt_scene_create: leaf_refs missing");
+    if (D->model_pretri_begin[D->model_count] != D->pretri_count)
+        return fail(RT_ERR_INVALID, "rt_scene_create: model_pretri_begin does not end at pretri_count");
+    if (D->model_vertex_begin[D->model_count] != D->vertex_count)
+        return fail(RT_ERR_INVALID, "rt_scene_create: model_vertex_begin does not end at vertex_count");
+
+    // ---- flatten the tree -------------------------------------------------------------------
+    struct HNode { float lo[3], hi[3]; int32_t index; uint32_t aux; };
+    static_assert(sizeof(HNode) == 32, "node record must be 32 bytes");
+    std::vector<HNode> nodes;
+    nodes.reserve(2 * static_cast<size_t>(D->inode_count) + 1);
+    auto leafRecord = [&](int32_t refIndex, HNode& n) -> int {
+        uint32_t const leaf = static_cast<uint32_t>(-(refIndex + 1));
+        if (leaf >= D->leaf_count) return fail(RT_ERR_INVALID, "rt_scene_create: leaf index out of range");
+        uint32_t const a = D->leaf_first_ref[leaf], b = D->leaf_first_ref[leaf + 1];
+        if (b < a || b > refCount || b == a) return fail(RT_ERR_INVALID, "rt_scene_create: bad leaf range");
+        n.index = -static_cast<int32_t>(a) - 1;
+        n.aux = b - a;
+        return RT_OK;
+    };
+    uint32_t maxDepth = 0;
+    {
+        HNode root{};
+        std::memcpy(root.lo, D->root_box, 12);
+        std::memcpy(root.hi, D->root_box + 3, 12);
+        nodes.push_back(root);
+        struct Item { uint32_t nodeSlot; int32_t refIndex; uint32_t depth; };
+        std::vector<Item> todo;
+        todo.push_back({0u, D->root_index, 0u});
+        std::vector<uint8_t> seen(D->inode_count, 0);
+        while (!todo.empty()) {
+            Item const it = todo.back();
+            todo.pop_back();
+            maxDepth = std::max(maxDepth, it.depth);
+            if (it.refIndex == 0) { nodes[it.nodeSlot].index = 0; nodes[it.nodeSlot].aux = 0; continue; }
+            if (it.refIndex < 0) {
+                HNode tmp = nodes[it.nodeSlot];
+                int const rc = leafRecord(it.refIndex, tmp);
+                if (rc != RT_OK) return rc;
+                nodes[it.nodeSlot] = tmp;
+                continue;
+            }
+            uint32_t const inode = static_cast<uint32_t>(it.refIndex - 1);
+            if (inode >= D->inode_count) return fail(RT_ERR_INVALID, "rt_scene_create: inode index out of range");
+            if (seen[inode]) return fail(RT_ERR_INVALID, "rt_scene_create: inode referenced twice");
+            seen[inode] = 1;
+            rt_inode const& in = D->inodes[inode];
+            if (in.axis > 2) return fail(RT_ERR_INVALID, "rt_scene_create: bad division axis");
+            // The kernels recompute the split plane as the centre of the node's own box.
+            HNode const self = nodes[it.nodeSlot];
+            float const plane = (self.lo[in.axis] + self.hi[in.axis]) / 2.0f;
+            if (!(in.pos_box[in.axis] == plane))
+                return fail(RT_ERR_INVALID, "rt_scene_create: tree is not split at box centres");
+            uint32_t const pair = static_cast<uint32_t>(nodes.size());
+            nodes[it.nodeSlot].index = static_cast<int32_t>(pair);
+            nodes[it.nodeSlot].aux = in.axis;
+            HNode a{}, b{};
+            std::memcpy(a.lo, in.neg_box, 12); std::memcpy(a.hi, in.neg_box + 3, 12);
+            std::memcpy(b.lo, in.pos_box, 12); std::memcpy(b.hi, in.pos_box + 3, 12);
+            nodes.push_back(a);
+            nodes.push_back(b);
+            // Depth-first, negative side first, so a subtree's records stay close together.
+            todo.push_back({pair + 1, in.pos_index, it.depth + 1});
+            todo.push_back({pair, in.neg_index, it.depth + 1});
+        }
+    }
+    if (maxDepth > RT_STACK_MAX)
+        return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth " + std::to_string(maxDepth) + " exceeds the "
+                    + std::to_string(RT_STACK_MAX) + "-entry traversal stack");
+    if (nodes.size() > 0x7FFFFFFFull) return fail(RT_ERR_LIMIT, "rt_scene_create: too many nodes");
+
+    // ---- leaf triangle records and per-triangle normals ---------------------------------------
+    std::vector<float> leafTris(16 * static_cast<size_t>(std::max<uint32_t>(refCount, 1)));
+    for (uint32_t r = 0; r < refCount; ++r) {
+        rt_tri_ref const ref = D->leaf_refs[r];
+        if (ref.mesh >= D->model_count) return fail(RT_ERR_INVALID, "rt_scene_create: leaf ref model out of range");
+        uint32_t const b = D->model_pretri_begin[ref.mesh], e = D->model_pretri_begin[ref.mesh + 1];
+        if (ref.tri >= e - b) return fail(RT_ERR_INVALID, "rt_scene_create: leaf ref triangle out of range");
+        uint32_t const gtri = b + ref.tri;
+        float const* pt = D->pretris + 12 * static_cast<size_t>(gtri);    // normal, v1, v1ToV3, v1ToV2
+        float* o = leafTris.data() + 16 * static_cast<size_t>(r);
+        std::memcpy(o, pt, 48);
+        uint32_t const ids[4] = {ref.mesh, ref.tri, gtri, 0u};
+        std::memcpy(o + 12, ids, 16);
+    }
+    std::vector<float> triNormals(12 * static_cast<size_t>(std::max<uint32_t>(D->pretri_count, 1)), 0.0f);
+    for (uint32_t m = 0; m < D->model_count; ++m) {
+        uint32_t const tb = D->model_pretri_begin[m], te = D->model_pretri_begin[m + 1];
+        uint32_t const vb = D->model_vertex_begin[m], ve = D->model_vertex_begin[m + 1];
+        if (te < tb || ve < vb) return fail(RT_ERR_INVALID, "rt_scene_create: offsets not ascending");
+        if (static_cast<uint64_t>(D->model_tri_begin[m]) + (te - tb) > D->base_tri_count)
+            return fail(RT_ERR_INVALID, "rt_scene_create: model triangle range outside base_tris");
+        for (uint32_t k = 0; k < te - tb; ++k) {
+            uint32_t const* idx = D->base_tris + 3 * (static_cast<size_t>(D->model_tri_begin[m]) + k);
+            float* o = triNormals.data() + 12 * static_cast<size_t>(tb + k);
+            for (int j = 0; j < 3; ++j) {
+                if (idx[j] >= ve - vb) return fail(RT_ERR_INVALID, "rt_scene_create: vertex index outside model");
+                std::memcpy(o + 3 * j, D->vertex_normals + 3 * static_cast<size_t>(vb + idx[j]), 12);
+            }
+        }
+    }
+
+    // ---- upload ---------------------------------------------------------------------------------
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device available");
+    if (device < 0 || device >= count) return fail(RT_ERR_INVALID, "rt_scene_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    rt_scene* s = new rt_scene;
+    s->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        s->cuCount = prop.multiProcessorCount;
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 64));
+        if (e != hipSuccess) return e;
+        s->deviceBytes += bytes;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    size_t const matBytes = 48 * static_cast<size_t>(std::max<uint32_t>(D->model_count, 1));
+    std::vector<float> mats(matBytes / 4, 0.0f);
+    std::memcpy(mats.data(), D->model_materials, 48 * static_cast<size_t>(D->model_count));
+    hipError_t e = upload(&s->dNodes, nodes.data(), nodes.size() * sizeof(HNode));
+    if (e == hipSuccess) e = upload(&s->dLeafTris, leafTris.data(), leafTris.size() * 4);
+    if (e == hipSuccess) e = upload(&s->dTriNormals, triNormals.data(), triNormals.size() * 4);
+    if (e == hipSuccess) e = upload(&s->dMaterials, mats.data(), matBytes);
+    if (e == hipSuccess) e = hipMalloc(&s->wsCounts, 4096);
+    if (e == hipSuccess) e = hipMalloc(&s->wsCounters, sizeof(Counters));
+    if (e != hipSuccess) {
+        rt_scene_destroy(s);
+        return fail(RT_ERR_HIP, std::string("rt_scene_create: upload failed: ") + hipGetErrorString(e));
+    }
+    s->dev.nodes = static_cast<const float4*>(s->dNodes);
+    s->dev.leafTris = static_cast<const float4*>(s->dLeafTris);
+    s->dev.triNormals = static_cast<const float4*>(s->dTriNormals);
+    s->dev.materials = static_cast<const float4*>(s->dMaterials);
+    s->nodeCount = static_cast<uint32_t>(nodes.size());
+    s->leafTriCount = refCount;
+    s->depth = maxDepth;
+    s->modelCount = D->model_count;
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    freeWorkspace(s);
+    for (void* p : {s->dNodes, s->dLeafTris, s->dTriNormals, s->dMaterials, s->wsCounts, s->wsCounters, s->wsOut})
+        if (p) (void)hipFree(p);
+    delete s;
+}
+
+int rt_scene_info(const rt_scene* s, uint64_t* device_bytes, uint32_t* node_count, uint32_t* leaf_tri_count,
+                  uint32_t* depth) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_info: null scene");
+    if (device_bytes) *device_bytes = s->deviceBytes;
+    if (node_count) *node_count = s->nodeCount;
+    if (leaf_tri_count) *leaf_tri_count = s->leafTriCount;
+    if (depth) *depth = s->depth;
+    return RT_OK;
+}
+
+int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_directions, uint64_t n, float t_min,
+                        int front_only, rt_hit* d_out, void* hip_stream) {
+    if (!s || (n && (!d_origins || !d_directions || !d_out))) return fail(RT_ERR_INVALID, "rt_intersect: null argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t const st = static_cast<hipStream_t>(hip_stream);
+    int const grid = gridFor(s, n);
+    if (front_only) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins, d_directions, n, t_min, d_out);
+    else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins, d_directions, n, t_min, d_out);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_intersect(rt_scene* s, const float* origins, const float* directions, uint64_t n, float t_min, int front_only,
+                 rt_hit* out) {
+    if (!s || (n && (!origins || !directions || !out))) return fail(RT_ERR_INVALID, "rt_intersect: null argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    float *dO = nullptr, *dD = nullptr;
+    rt_hit* dH = nullptr;
+    int rc = RT_OK;
+    hipError_t e = hipMalloc(&dO, n * 12);
+    if (e == hipSuccess) e = hipMalloc(&dD, n * 12);
+    if (e == hipSuccess) e = hipMalloc(&dH, n * sizeof(rt_hit));
+    if (e == hipSuccess) e = hipMemcpy(dO, origins, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dD, directions, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = rt_intersect_device(s, dO, dD, n, t_min, front_only, dH, nullptr);
+        if (rc == RT_OK) e = hipDeviceSynchronize();
+        if (rc == RT_OK && e == hipSuccess) e = hipMemcpy(out, dH, n * sizeof(rt_hit), hipMemcpyDeviceToHost);
+    }
+    if (dO) (void)hipFree(dO);
+    if (dD) (void)hipFree(dD);
+    if (dH) (void)hipFree(dH);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_intersect: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* stats, void* hip_stream) {
+    if (!s || !p || !d_out) return fail(RT_ERR_INVALID, "rt_render: null argument");
+    if (p->w == 0 || p->h == 0 || p->spp == 0) return fail(RT_ERR_INVALID, "rt_render: empty rectangle or zero spp");
+    if (static_cast<uint64_t>(p->x0) + p->w > p->width || static_cast<uint64_t>(p->y0) + p->h > p->height)
+        return fail(RT_ERR_INVALID, "rt_render: rectangle outside the image");
+    if (static_cast<uint64_t>(p->width) * p->height > 0xFFFFFFFFull)
+        return fail(RT_ERR_LIMIT, "rt_render: more than 2^32 pixels");
+    if (p->bounce_limit > 1000) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit above 1000");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t const st = static_cast<hipStream_t>(hip_stream);
+    auto const t0 = std::chrono::steady_clock::now();
+
+    uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
+    uint64_t const maxPaths = p->max_batch_paths ? p->max_batch_paths : (16ull << 20);
+    uint32_t const spb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(p->spp, maxPaths / pixels)));
+    uint64_t const batchPaths = pixels * spb;
+    if (batchPaths > 0xFFFFFFF0ull) return fail(RT_ERR_LIMIT, "rt_render: rectangle too large for one batch");
+
+    if (s->wsPaths < batchPaths || s->wsPixels < pixels) {
+        HIP_TRY(hipStreamSynchronize(st));
+        freeWorkspace(s);
+        HIP_TRY(hipMalloc(&s->wsA, batchPaths * 16));
+        HIP_TRY(hipMalloc(&s->wsB, batchPaths * 16));
+        HIP_TRY(hipMalloc(&s->wsC, batchPaths * 16));
+        HIP_TRY(hipMalloc(&s->wsHit, batchPaths * 16));
+        HIP_TRY(hipMalloc(&s->wsQ0, batchPaths * 4));
+        HIP_TRY(hipMalloc(&s->wsQ1, batchPaths * 4));
+        HIP_TRY(hipMalloc(&s->wsAccum, pixels * 12));
+        s->wsPaths = batchPaths;
+        s->wsPixels = pixels;
+    }
+    uint32_t const bounceCount = p->bounce_limit + 1;      // intersections per path, src/render.hpp:88
+    if ((bounceCount + 2) * 4 > 4096) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit too large");
+
+    PathState P;
+    P.A = static_cast<float4*>(s->wsA); P.B = static_cast<float4*>(s->wsB); P.C = static_cast<float4*>(s->wsC);
+    P.hit = static_cast<float4*>(s->wsHit);
+    P.queue[0] = static_cast<uint32_t*>(s->wsQ0); P.queue[1] = static_cast<uint32_t*>(s->wsQ1);
+    P.counts = static_cast<uint32_t*>(s->wsCounts);
+    Counters* gc = static_cast<Counters*>(s->wsCounters);
+
+    RenderConst R;
+    std::memcpy(R.camPos, p->camera_position, 12);
+    std::memcpy(R.m, p->pixel_to_ray, 36);
+    R.width = p->width; R.x0 = p->x0; R.y0 = p->y0; R.w = p->w; R.h = p->h;
+    R.bounceLimit = p->bounce_limit; R.tMin = p->t_min;
+    R.key0 = static_cast<uint32_t>(p->seed); R.key1 = static_cast<uint32_t>(p->seed >> 32);
+
+    bool const countWork = (p->flags & RT_FLAG_COUNT_WORK) != 0;
+    bool const profile = (p->flags & RT_FLAG_PROFILE_KERNELS) != 0;
+    std::vector<hipEvent_t> events;           // pairs; kind in evKind
+    std::vector<int> evKind;
+    auto mark = [&](int kind) {
+        if (!profile) return;
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        (void)hipEventRecord(ev, st);
+        events.push_back(ev);
+        evKind.push_back(kind);
+    };
+
+    HIP_TRY(hipMemsetAsync(gc, 0, sizeof(Counters), st));
+    HIP_TRY(hipMemsetAsync(s->wsAccum, 0, pixels * 12, st));
+    uint32_t batches = 0, traceLaunches = 0;
+    for (uint32_t done = 0; done < p->spp; done += spb) {
+        uint32_t const nb = std::min(spb, p->spp - done);
+        uint32_t const paths = static_cast<uint32_t>(pixels * nb);
+        int const grid = gridFor(s, paths);
+        HIP_TRY(hipMemsetAsync(P.counts, 0, (bounceCount + 2) * 4, st));
+        mark(0);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, R, P, static_cast<uint32_t>(pixels), done, paths);
+        mark(-1);
+        for (uint32_t b = 0; b < bounceCount; ++b) {
+            mark(1);
+            if (countWork) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc);
+            else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc);
+            mark(-1);
+            mark(2);
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, R, P, b, done, static_cast<uint32_t>(pixels), gc);
+            mark(-1);
+            ++traceLaunches;
+        }
+        int const last = done + nb >= p->spp;
+        mark(3);
+        hipLaunchKernelGGL(k_accumulate, dim3(static_cast<unsigned>((pixels + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK),
+                           0, st, P, static_cast<float*>(s->wsAccum), static_cast<uint32_t>(pixels), nb, bounceCount, last,
+                           static_cast<float>(p->spp), d_out, gc);
+        mark(-1);
+        ++batches;
+    }
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        Counters hc;
+        HIP_TRY(hipMemcpyAsync(&hc, gc, sizeof hc, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memset(stats, 0, sizeof *stats);
+        stats->paths = hc.paths; stats->segments = hc.segments; stats->shaded_hits = hc.shadedHits;
+        stats->box_tests = hc.boxTests; stats->tris_tested = hc.trisTested; stats->leaf_visits = hc.leafVisits;
+        stats->inode_visits = hc.inodeVisits;
+        stats->trace_launches = traceLaunches; stats->batches = batches;
+        if (profile) {
+            double acc[4] = {0, 0, 0, 0};
+            for (size_t i = 0; i + 1 < events.size(); i += 2) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, events[i], events[i + 1]) == hipSuccess && evKind[i] >= 0) acc[evKind[i]] += ms;
+            }
+            stats->ms_raygen = acc[0]; stats->ms_trace = acc[1]; stats->ms_shade = acc[2]; stats->ms_accumulate = acc[3];
+        }
+        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+    return RT_OK;
+}
+
+int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* stats) {
+    if (!s || !p || !out_rgb) return fail(RT_ERR_INVALID, "rt_render: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
+    if (s->wsOutPixels < pixels) {
+        if (s->wsOut) (void)hipFree(s->wsOut);
+        s->wsOut = nullptr;
+        s->wsOutPixels = 0;
+        HIP_TRY(hipMalloc(&s->wsOut, std::max<uint64_t>(pixels, 1) * 12));
+        s->wsOutPixels = pixels;
+    }
+    rt_stats local;
+    int const rc = rt_render_device(s, p, static_cast<float*>(s->wsOut), stats ? stats : &local, nullptr);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpy(out_rgb, s->wsOut, pixels * 12, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// Test hook: evaluates one scalar building block on the GPU for n inputs (see k_selftest).
+int rt_selftest_math(int op, const float* a, const float* b, uint32_t n, float* out) {
+    if (!a || !b || !out || n == 0) return fail(RT_ERR_INVALID, "rt_selftest_math: null argument");
+    uint32_t const outPer = (op == 2 || op == 3) ? 2 : 1;
+    float *dA = nullptr, *dB = nullptr, *dO = nullptr;
+    hipError_t e = hipMalloc(&dA, n * 4ull);
+    if (e == hipSuccess) e = hipMalloc(&dB, n * 4ull);
+    if (e == hipSuccess) e = hipMalloc(&dO, n * 4ull * outPer);
+    if (e == hipSuccess) e = hipMemcpy(dA, a, n * 4ull, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dB, b, n * 4ull, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, dA, dB, n, dO);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dO, n * 4ull * outPer, hipMemcpyDeviceToHost);
+    if (dA) (void)hipFree(dA);
+    if (dB) (void)hipFree(dB);
+    if (dO) (void)hipFree(dO);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_selftest_math: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"

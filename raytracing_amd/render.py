@@ -1,0 +1,155 @@
+"""Render entry points over the C ABI of librt_amd.so (include/rt_amd.h).
+
+Mirrors src/render.hpp: `RayTraceData`, `RenderData`, `render()`; `BSPTree.line_tri_nearest_intersection`
+is `DeviceScene.intersect`.  All computation happens in the HIP kernels; nothing here falls back to
+the CPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import c_u32, c_u64, c_f32, c_int, ptr
+
+PIXEL_SAMPLE_RATE = 2048            # src/render.hpp:47
+RAY_INTERSECTION_T_MIN = 1e-3       # src/render.hpp:48
+RAY_BOUNCE_LIMIT = 8                # src/render.hpp:49
+
+
+class RayTraceData:
+    """src/render.hpp:28-35 with the model->mesh and model->material permutations applied."""
+
+    def __init__(self, scene):
+        if scene.bsp_tree is None:
+            scene.preprocess()
+        self.scene = scene
+        mm = np.asarray(scene.models.meshes, np.uint32)
+        self.bsp_tree = scene.bsp_tree
+        self.vertex_normals = scene.instantiated_meshes.vertex_normals
+        self.vertex_begin = scene.instantiated_meshes.vertex_begin
+        self.tris = scene.meshes.tris
+        self.model_tri_begin = np.ascontiguousarray(scene.meshes.tri_ranges[mm, 0], np.uint32)
+        self.materials = np.ascontiguousarray(
+            scene.preprocessed_materials[np.asarray(scene.models.materials, np.int64)], np.float32)
+        self.pretris = scene.preprocessed_tris.tris
+        self.pretri_begin = scene.preprocessed_tris.tri_begin
+
+
+class DeviceScene:
+    """A scene resident in HBM (rt_scene).  One per GPU."""
+
+    def __init__(self, ray_trace_data, device=0):
+        L = _lib.lib()
+        d = ray_trace_data
+        t = d.bsp_tree
+        # keep references alive for the duration of the call
+        keep = dict(inodes=np.ascontiguousarray(t.inodes), first=np.ascontiguousarray(t.leaf_first_ref, np.uint32),
+                    refs=np.ascontiguousarray(t.leaf_refs), pretris=np.ascontiguousarray(d.pretris, np.float32),
+                    ptb=np.ascontiguousarray(d.pretri_begin, np.uint32),
+                    vn=np.ascontiguousarray(d.vertex_normals, np.float32),
+                    vb=np.ascontiguousarray(d.vertex_begin, np.uint32), bt=np.ascontiguousarray(d.tris, np.uint32),
+                    mtb=np.ascontiguousarray(d.model_tri_begin, np.uint32),
+                    mats=np.ascontiguousarray(d.materials, np.float32))
+        desc = _lib.RtSceneDesc()
+        desc.root_box[:] = [float(x) for x in t.root_box]
+        desc.root_index = t.root_index
+        desc.inodes, desc.inode_count = ptr(keep["inodes"]), t.inode_count
+        desc.leaf_first_ref, desc.leaf_refs, desc.leaf_count = ptr(keep["first"]), ptr(keep["refs"]), t.leaf_count
+        desc.pretris, desc.model_pretri_begin, desc.pretri_count = ptr(keep["pretris"]), ptr(keep["ptb"]), len(keep["pretris"])
+        desc.vertex_normals, desc.model_vertex_begin, desc.vertex_count = ptr(keep["vn"]), ptr(keep["vb"]), len(keep["vn"])
+        desc.base_tris, desc.model_tri_begin, desc.base_tri_count = ptr(keep["bt"]), ptr(keep["mtb"]), len(keep["bt"])
+        desc.model_materials, desc.model_count = ptr(keep["mats"]), len(keep["mats"])
+        self._h = _lib.vp()
+        _lib.check(L.rt_scene_create(ctypes.byref(desc), c_int(device), ctypes.byref(self._h)))
+        self.device = device
+        nbytes, nodes, ltris, depth = c_u64(), c_u32(), c_u32(), c_u32()
+        _lib.check(L.rt_scene_info(self._h, ctypes.byref(nbytes), ctypes.byref(nodes), ctypes.byref(ltris),
+                                   ctypes.byref(depth)))
+        self.device_bytes, self.node_count, self.leaf_tri_count, self.depth = (nbytes.value, nodes.value,
+                                                                               ltris.value, depth.value)
+
+    def close(self):
+        if self._h:
+            _lib.lib().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # BSPTree::lineTriNearestIntersection<Surfaces>, src/bsp.hpp:50-145
+    def intersect(self, origins, directions, t_min=RAY_INTERSECTION_T_MIN, front_only=True):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        out = np.zeros(len(o), _lib.HIT_DTYPE)
+        _lib.check(_lib.lib().rt_intersect(self._h, ptr(o), ptr(d), c_u64(len(o)), c_f32(t_min),
+                                           c_int(int(front_only)), ptr(out)))
+        return out
+
+    def intersect_device(self, d_origins, d_directions, n, d_out, t_min=RAY_INTERSECTION_T_MIN, front_only=True,
+                         stream=None):
+        """Device-pointer form (integers or objects with data_ptr())."""
+        def dp(x):
+            return ctypes.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        _lib.check(_lib.lib().rt_intersect_device(self._h, dp(d_origins), dp(d_directions), c_u64(n), c_f32(t_min),
+                                                  c_int(int(front_only)), dp(d_out),
+                                                  ctypes.c_void_p(stream or 0)))
+
+    def make_params(self, width, height, camera_position, pixel_to_ray, spp=PIXEL_SAMPLE_RATE,
+                    bounce_limit=RAY_BOUNCE_LIMIT, t_min=RAY_INTERSECTION_T_MIN, seed=0x5EED, rect=None, flags=0,
+                    max_batch_paths=0):
+        p = _lib.RtRenderParams()
+        p.width, p.height = width, height
+        p.x0, p.y0, p.w, p.h = rect if rect is not None else (0, 0, width, height)
+        p.spp, p.bounce_limit, p.t_min, p.seed = spp, bounce_limit, t_min, seed
+        p.camera_position[:] = [float(x) for x in camera_position]
+        p.pixel_to_ray[:] = [float(x) for x in pixel_to_ray]
+        p.flags, p.max_batch_paths = flags, max_batch_paths
+        return p
+
+    def render(self, params):
+        """rt_render: returns (image[h, w, 3] float32 on the host, stats dict)."""
+        img = np.zeros((params.h, params.w, 3), np.float32)
+        st = _lib.RtStats()
+        _lib.check(_lib.lib().rt_render(self._h, ctypes.byref(params), ptr(img), ctypes.byref(st)))
+        return img, st.as_dict()
+
+    def render_device(self, params, d_out, stream=None, want_stats=True):
+        """rt_render_device: writes w*h*3 floats at device pointer d_out; returns stats (syncs) or None."""
+        st = _lib.RtStats()
+        dp = ctypes.c_void_p(d_out.data_ptr() if hasattr(d_out, "data_ptr") else int(d_out))
+        _lib.check(_lib.lib().rt_render_device(self._h, ctypes.byref(params), dp,
+                                               ctypes.byref(st) if want_stats else None,
+                                               ctypes.c_void_p(stream or 0)))
+        return st.as_dict() if want_stats else None
+
+
+class RenderData:
+    """src/render.hpp:38-44."""
+
+    def __init__(self, image_width, image_height, camera_position, pixel_to_ray_transform, ray_trace_data):
+        self.image_width, self.image_height = image_width, image_height
+        self.camera_position = np.asarray(camera_position, np.float32)
+        self.pixel_to_ray_transform = np.asarray(pixel_to_ray_transform, np.float32)
+        self.ray_trace_data = ray_trace_data
+        self._device_scene = None
+
+    def device_scene(self, device=0):
+        if self._device_scene is None:
+            self._device_scene = DeviceScene(self.ray_trace_data, device)
+        return self._device_scene
+
+
+def render(data, image, spp=PIXEL_SAMPLE_RATE, bounce_limit=RAY_BOUNCE_LIMIT, seed=0x5EED, device=0):
+    """render(RenderData const&, Span<glm::vec3>) of src/render.hpp:215-234: fills `image`
+    (width*height x 3 float32, row-major) with the mean radiance per pixel.  Returns the stats."""
+    assert image.size == data.image_width * data.image_height * 3        # src/render.hpp:216
+    ds = data.device_scene(device)
+    p = ds.make_params(data.image_width, data.image_height, data.camera_position, data.pixel_to_ray_transform,
+                       spp=spp, bounce_limit=bounce_limit, seed=seed)
+    img, stats = ds.render(p)
+    np.copyto(image.reshape(data.image_height, data.image_width, 3), img)
+    return stats
