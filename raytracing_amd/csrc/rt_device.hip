@@ -545,8 +545,10 @@ uint32_t rt_abi_version(void) { return 1; }
 
 int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     if (!D || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
-    if (!D->model_pretri_begin || !D->model_vertex_begin || !D->model_tri_begin || !D->model_materials || !D->pretris
-        || !D->vertex_normals || !D->base_tris || !D->leaf_first_ref)
+    if (!D->model_pretri_begin || !D->model_vertex_begin || !D->leaf_first_ref)
+        return fail(RT_ERR_INVALID, "rt_scene_create: null offset array in description");
+    if ((D->model_count && (!D->model_tri_begin || !D->model_materials)) || (D->pretri_count && !D->pretris)
+        || (D->vertex_count && !D->vertex_normals) || (D->base_tri_count && !D->base_tris))
         return fail(RT_ERR_INVALID, "rt_scene_create: null array in description");
     if (D->inode_count && !D->inodes) return fail(RT_ERR_INVALID, "rt_scene_create: inodes missing");
     uint32_t const refCount = D->leaf_first_ref[D->leaf_count];

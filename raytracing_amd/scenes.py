@@ -102,38 +102,31 @@ def grid_cube(n):
     return np.concatenate(pos).astype(F), np.concatenate(nrm).astype(F), np.concatenate(tris).astype(np.uint32)
 
 
-def displaced_sphere(nu, nv, seed=1234, octaves=5, amplitude=0.18):
-    """Closed unit-radius surface with multi-octave sinusoidal displacement: 2*nu*(nv-1) triangles,
-    outward winding, smooth vertex normals."""
+def displaced_sphere(n, seed=1234, octaves=5, amplitude=0.18):
+    """Closed surface: a cube whose six faces are n x n grids, projected onto the unit sphere and
+    displaced radially by a multi-octave product of sines.  12*n*n triangles, outward winding, smooth
+    vertex normals, vertex valence at most 6 (a fan of more than Leaf::MAX_TRIS triangles around one
+    vertex can never be separated by the reference's builder, src/bsp.hpp:206-208)."""
     rng = np.random.default_rng(seed)
-    u = np.linspace(0.0, 2.0 * np.pi, nu, endpoint=False)
-    v = np.linspace(0.0, np.pi, nv + 1)
-    vv, uu = np.meshgrid(v[1:-1], u, indexing="ij")                      # interior rings
-    d = np.stack([np.sin(vv) * np.cos(uu), np.cos(vv), np.sin(vv) * np.sin(uu)], -1).reshape(-1, 3)
-    dirs = np.concatenate([[[0, 1, 0]], d, [[0, -1, 0]]])                # poles first/last
+    pos, _, tris = grid_cube(n)
+    dirs = pos.astype(np.float64)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
     radius = np.ones(len(dirs))
     for o in range(octaves):
         k = rng.normal(size=(3, 3)) * (2.0 ** o) * 1.5
         phase = rng.uniform(0, 2 * np.pi, 3)
         radius += amplitude / (2.0 ** o) * np.prod(np.sin(dirs @ k.T + phase), axis=1)
-    pos = dirs * radius[:, None]
-    rings = nv - 1
-    idx = 1 + np.arange(rings * nu).reshape(rings, nu)
-    nxt = np.roll(idx, -1, axis=1)
-    a, b, c, dd = idx[:-1], nxt[:-1], idx[1:], nxt[1:]
-    body = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([b, dd, c], -1).reshape(-1, 3)])
-    top = np.stack([np.zeros(nu, np.int64), nxt[0], idx[0]], 1)
-    bottom = np.stack([np.full(nu, len(pos) - 1), idx[-1], nxt[-1]], 1)
-    tris = np.concatenate([top, body, bottom]).astype(np.uint32)
-    fn = np.cross(pos[tris[:, 1]] - pos[tris[:, 0]], pos[tris[:, 2]] - pos[tris[:, 0]])
-    if np.mean(np.einsum("ij,ij->i", fn, pos[tris[:, 0]])) < 0:           # make the winding outward
-        tris = tris[:, [0, 2, 1]]
-        fn = -fn
-    vn = np.zeros_like(pos)
-    for k in range(3):
-        np.add.at(vn, tris[:, k], fn)
+    p = dirs * radius[:, None]
+    fn = np.cross(p[tris[:, 1]] - p[tris[:, 0]], p[tris[:, 2]] - p[tris[:, 0]])
+    # weld the duplicated cube-edge vertices when averaging normals so shading is smooth across faces
+    _, weld = np.unique(np.round(dirs * 1e6).astype(np.int64), axis=0, return_inverse=True)
+    weld = weld.ravel()
+    acc = np.zeros((weld.max() + 1, 3))
+    for c in range(3):
+        np.add.at(acc, weld[tris[:, c]], fn)
+    vn = acc[weld]
     vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-30)
-    return pos.astype(F), vn.astype(F), tris
+    return p.astype(F), vn.astype(F), tris
 
 
 # ---- benchmark scenes -----------------------------------------------------------------------------
@@ -167,9 +160,8 @@ def dragon_scale_scene(target_tris=900_000, seed=1234, copies=1):
     """One displaced closed surface of about target_tris triangles (stand-in for a scanned mesh such as
     the Stanford dragon, which is not available offline) over a floor, lit by two emitter quads.
     copies > 1 instantiates the surface several times (multi-mesh, about copies*target_tris triangles)."""
-    nv = max(8, int(round(np.sqrt(target_tris / 4.0))))
-    nu = 2 * nv
-    surface = displaced_sphere(nu, nv, seed)
+    n = max(2, int(round(np.sqrt(target_tris / 12.0))))
+    surface = displaced_sphere(n, seed)
     meshes = Meshes([surface, grid_plane(8), grid_plane(1)])
     materials = [Material((0.25, 0.25, 0.25), 0.9, 0.0), Material((0.9, 0.75, 0.4), 0.3, 0.6),
                  Material((0, 0, 0), 0.9, 0.0, (20.0, 18.0, 15.0)), Material((0, 0, 0), 0.9, 0.0, (6.0, 8.0, 12.0))]

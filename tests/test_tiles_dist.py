@@ -1,0 +1,89 @@
+"""Multi-rank path on CPU: band assignment and the gather of finished bands to rank 0 over
+torch.distributed (gloo, world_size 2).  The renderer is replaced by a function of the global pixel
+coordinates so the assembled frame has a known answer; the GPU render itself is covered by -m gpu."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from raytracing_amd import tiles
+
+
+@pytest.mark.parametrize("height,world,bpr", [(1080, 1, 4), (1080, 2, 4), (1080, 8, 4), (2160, 8, 4), (7, 8, 4), (5, 2, 1)])
+def test_bands_partition_the_frame(height, world, bpr):
+    bands = tiles.band_rows(height, world, bpr)
+    assert bands[0][0] == 0 and sum(r for _, r in bands) == height
+    for (y0, r), (y1, _) in zip(bands[:-1], bands[1:]):
+        assert y0 + r == y1
+    seen = []
+    for rank in range(world):
+        seen += [(y0, r) for _, y0, r in tiles.rank_bands(height, world, rank, bpr)]
+    assert sorted(seen) == bands
+    rows = [sum(r for _, _, r in tiles.rank_bands(height, world, k, bpr)) for k in range(world)]
+    assert max(rows) == tiles.max_rank_rows(height, world, bpr)
+    if height >= world * bpr:
+        assert max(rows) - min(rows) <= bpr          # balanced to within one row per band
+
+
+def _expected(width, height):
+    y, x = np.mgrid[0:height, 0:width]
+    return np.stack([x + 1000.0 * y, x * 0.5, y * 0.25], -1).astype(np.float32)
+
+
+def _worker(rank, world, port, width, height, bpr, result):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        want = torch.from_numpy(_expected(width, height))
+        buf = torch.zeros(tiles.max_rank_rows(height, world, bpr) * width * 3)
+
+        def render_rect(x0, y0, w, h, out):
+            out.copy_(want[y0:y0 + h, x0:x0 + w].reshape(-1))
+            return {"segments": w * h, "ms_trace": 1.0}
+
+        st = tiles.render_sharded(render_rect, width, height, rank, world, buf, bpr)
+        frame = tiles.gather_frame(buf, width, height, rank, world, bpr, dist)
+        total = torch.tensor([float(st["segments"])])
+        dist.all_reduce(total)
+        if rank == 0:
+            result["ok"] = bool(torch.equal(frame, want)) and int(total.item()) == width * height
+        else:
+            assert frame is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("width,height,bpr", [(64, 37, 4), (33, 5, 2)])
+def test_gather_reassembles_frame_world_size_2(width, height, bpr):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    result = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, width, height, bpr, result)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert result.get("ok") is True
+
+
+def test_single_rank_is_a_view():
+    import torch
+    w, h = 16, 9
+    want = torch.from_numpy(_expected(w, h))
+    buf = torch.zeros(tiles.max_rank_rows(h, 1) * w * 3)
+
+    def render_rect(x0, y0, ww, hh, out):
+        out.copy_(want[y0:y0 + hh, x0:x0 + ww].reshape(-1))
+        return {}
+
+    tiles.render_sharded(render_rect, w, h, 0, 1, buf)
+    assert torch.equal(tiles.gather_frame(buf, w, h, 0, 1), want)
