@@ -76,6 +76,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
                               "(there is no fallback implementation)")
+        # librt_amd.so needs the HIP runtime by soname (libamdhip64.so.7).  PyTorch ships its own copy; two
+        # HIP runtimes in one process cannot both open the GPU, so when torch is installed its copy is
+        # loaded first and the dynamic loader resolves our dependency to that same object.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         L.rt_last_error.restype = ctypes.c_char_p
         L.rt_abi_version.restype = c_u32
