@@ -56,6 +56,7 @@ struct DevScene {
     const float4* leafTris;
     const float4* triNormals;
     const float4* materials;
+    int fastDivision;      // every box plane coordinate is 0 or in [2^-75, 2^100): see divByRecip
 };
 
 struct Counters {
@@ -93,25 +94,51 @@ __device__ __forceinline__ V3 crossF(V3 a, V3 b) {
     return mk(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x)));
 }
 
-// One face of the reference's six-face box test (src/geometry.hpp:136-212).
-__device__ __forceinline__ bool faceHit(float denom, float numer, float oa, float da, float loa, float hia, float ob,
-                                        float db, float lob, float hib) {
-    if (fabsf(denom) < 1e-6f) return false;
-    float const t = numer / denom;
-    if (!(t >= 0.0f)) return false;
-    float const pa = oa + t * da;
-    if (!(pa >= loa && pa <= hia)) return false;
-    float const pb = ob + t * db;
-    return pb >= lob && pb <= hib;
+// Correctly rounded a/b from y = RN(1/b), without the hardware division sequence.
+//   q0 = RN(a*y); q1 = RN(q0 + (a - b*q0)*y) is a faithful quotient; one more correction step gives
+//   RN(a/b) for every rounding direction (Markstein, "Computation of elementary functions on the IBM
+//   RISC System/6000 processor", 1990: a faithful quotient corrected once with the correctly rounded
+//   reciprocal is correctly rounded).  The residuals a - b*q are exact FMA results as long as
+//   2^-100 <= |a| (or a == 0) and nothing overflows; callers guarantee that range (see RayRecips).
+__device__ __forceinline__ float divByRecip(float a, float b, float y) {
+    float const q0 = a * y;
+    float const q1 = __fmaf_rn(__fmaf_rn(-b, q0, a), y, q0);
+    return __fmaf_rn(__fmaf_rn(-b, q1, a), y, q1);
 }
 
-__device__ __forceinline__ bool lineBox(V3 o, V3 d, V3 lo, V3 hi) {
-    return faceHit(-d.x, o.x - lo.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z)
-        || faceHit(d.x, hi.x - o.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z)
-        || faceHit(-d.y, o.y - lo.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z)
-        || faceHit(d.y, hi.y - o.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z)
-        || faceHit(-d.z, o.z - lo.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y)
-        || faceHit(d.z, hi.z - o.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y);
+// One face of the reference's six-face box test (src/geometry.hpp:136-212): the line meets the face
+// plane at t = numer/denom with |denom| >= 1e-6 and t >= 0, and the point origin + t*direction
+// (unfused) lies inside the face rectangle, bounds inclusive.  Written without branches: the six faces
+// are evaluated by every lane and OR-ed, which is the same boolean as the reference's early-out chain
+// and keeps the 64 lanes of a wave in lock step.  EXACT_DIV selects the hardware division (any input
+// range) over divByRecip (inputs in the guarded range).
+template <bool EXACT_DIV>
+__device__ __forceinline__ bool faceHit(float denom, float recip, float numer, float oa, float da, float loa,
+                                        float hia, float ob, float db, float lob, float hib) {
+    float const t = EXACT_DIV ? numer / denom : divByRecip(numer, denom, recip);
+    float const pa = oa + t * da;
+    float const pb = ob + t * db;
+    return (fabsf(denom) >= 1e-6f) & (t >= 0.0f) & (pa >= loa) & (pa <= hia) & (pb >= lob) & (pb <= hib);
+}
+
+// r = RN(1/d) per axis, computed once per line with true divisions.
+template <bool EXACT_DIV>
+__device__ __forceinline__ bool lineBox(V3 o, V3 d, V3 r, V3 lo, V3 hi) {
+    bool const a = faceHit<EXACT_DIV>(-d.x, -r.x, o.x - lo.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z);
+    bool const b = faceHit<EXACT_DIV>(d.x, r.x, hi.x - o.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z);
+    bool const c = faceHit<EXACT_DIV>(-d.y, -r.y, o.y - lo.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z);
+    bool const e = faceHit<EXACT_DIV>(d.y, r.y, hi.y - o.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z);
+    bool const f = faceHit<EXACT_DIV>(-d.z, -r.z, o.z - lo.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y);
+    bool const g = faceHit<EXACT_DIV>(d.z, r.z, hi.z - o.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y);
+    return a | b | c | e | f | g;
+}
+
+// divByRecip is exact for this line against every box of a scene whose plane coordinates c satisfy
+// c == 0 or 2^-75 <= |c| < 2^100 (checked on the host when the scene is created) if each origin
+// coordinate obeys the same bounds: then every numerator origin - c is zero or at least 2^-100.
+__device__ __forceinline__ bool coordInFastRange(float x) {
+    float const a = fabsf(x);
+    return (a == 0.0f) | ((a >= 0x1p-75f) & (a < 0x1p100f));
 }
 
 struct HitRec {
@@ -119,25 +146,82 @@ struct HitRec {
     uint32_t ref;       // index of the leaf triangle record, 0xFFFFFFFF = miss
 };
 
-// Nearest intersection, src/bsp.hpp:50-145, with the recursion unrolled onto a per-lane stack of
-// deferred far children.  Visiting order, the per-node box test, the first-leaf-with-a-hit
-// termination and the in-leaf-box acceptance test are those of the reference.
-template <bool FRONT_ONLY, bool COUNT>
-__device__ __forceinline__ HitRec closestHit(const DevScene& S, V3 o, V3 d, float tMin, Counters& c) {
+// Nearest intersection (src/bsp.hpp:50-145) for a stream of n lines, one lane per line.
+//
+// The recursion of the reference is unrolled onto a per-lane stack of deferred far children.  Visiting
+// order, the per-node box test, the first-leaf-with-a-hit termination and the in-leaf-box acceptance
+// test are those of the reference.
+//
+// Shape: persistent "while-while" with refill.  Each lane alternates between (1) walking interior
+// nodes until it stands on a leaf whose box its line meets and (2) testing that leaf's triangles;
+// lanes of a wave that reach a leaf early wait for the others so that phase 2 runs with most lanes
+// active.  A lane whose line is finished stores the result and takes the next line of the stream at
+// the top of the loop, so a wave is not held hostage by its longest line.  Lines are handed out in
+// chunks of RT_FETCH_CHUNK per wave (one global atomic per chunk); inside a chunk lanes take lines by
+// their rank among the idle lanes.
+//   load(i, o, d)        reads line i of the stream
+//   store(i, hit, o, d)  receives its nearest hit (hit.ref == 0xFFFFFFFF: none)
+#define RT_FETCH_CHUNK 256u
+template <bool FRONT_ONLY, bool COUNT, class Load, class Store>
+__device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint32_t* __restrict__ nextLine, float tMin,
+                                            Counters& c, Load load, Store store) {
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t const lane = threadIdx.x & 63u;
+    unsigned long long const below = (1ull << lane) - 1ull;
     uint32_t stack[RT_STACK_MAX];
+    // wave-uniform fetch state
+    uint32_t chunkNext = 0, chunkEnd = 0;
+    bool drained = false;
+    // per-lane line state
+    bool active = false;
+    uint32_t line = 0, cur = NONE;
     int sp = 0;
-    uint32_t cur = 0;
+    V3 o = mk(0.0f, 0.0f, 0.0f), d = o, r = o;
+    bool fastDiv = false;
     HitRec best;
-    best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = 0xFFFFFFFFu;
+    best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
+
     for (;;) {
-        float4 const q0 = S.nodes[2 * cur];
-        float4 const q1 = S.nodes[2 * cur + 1];
-        V3 const lo = mk(q0.x, q0.y, q0.z), hi = mk(q0.w, q1.x, q1.y);
-        if (COUNT) c.boxTests++;
-        if (lineBox(o, d, lo, hi)) {
+        // ---- refill idle lanes ------------------------------------------------------------------
+        unsigned long long idle = __ballot(!active);
+        while (idle != 0ull && !drained) {
+            if (chunkNext == chunkEnd) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(nextLine, RT_FETCH_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) { drained = true; break; }
+                chunkNext = base;
+                chunkEnd = min(base + RT_FETCH_CHUNK, n);
+            }
+            uint32_t const avail = chunkEnd - chunkNext;
+            uint32_t const rank = static_cast<uint32_t>(__popcll(idle & below));
+            if (!active && rank < avail) {
+                line = chunkNext + rank;
+                load(line, o, d);
+                r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                fastDiv = S.fastDivision && coordInFastRange(o.x) && coordInFastRange(o.y) && coordInFastRange(o.z);
+                sp = 0; cur = 0;
+                best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
+                active = true;
+            }
+            chunkNext += min(static_cast<uint32_t>(__popcll(idle)), avail);
+            idle = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) break;
+        if (!active) continue;
+
+        // ---- phase 1: interior nodes until a leaf is reached or nothing is left ------------------
+        uint32_t leafFirst = 0, leafCount = 0;
+        V3 lo = mk(0.0f, 0.0f, 0.0f), hi = lo;
+        while (cur != NONE) {
+            float4 const q0 = S.nodes[2 * cur];
+            float4 const q1 = S.nodes[2 * cur + 1];
+            lo = mk(q0.x, q0.y, q0.z); hi = mk(q0.w, q1.x, q1.y);
+            if (COUNT) c.boxTests++;
             int const index = __float_as_int(q1.z);
             uint32_t const aux = __float_as_uint(q1.w);
-            if (index > 0) {
+            bool const meets = fastDiv ? lineBox<false>(o, d, r, lo, hi) : lineBox<true>(o, d, r, lo, hi);
+            if (meets && index > 0) {
                 if (COUNT) c.inodeVisits++;
                 float const la = aux == 0 ? lo.x : (aux == 1 ? lo.y : lo.z);
                 float const ha = aux == 0 ? hi.x : (aux == 1 ? hi.y : hi.z);
@@ -149,39 +233,56 @@ __device__ __forceinline__ HitRec closestHit(const DevScene& S, V3 o, V3 d, floa
                 cur = positiveNear ? base + 1 : base;                       // near child
                 continue;
             }
-            if (index < 0) {
-                if (COUNT) { c.leafVisits++; c.trisTested += aux; }
-                uint32_t const first = static_cast<uint32_t>(-(index + 1));
-                bool has = false;
-                for (uint32_t j = 0; j < aux; ++j) {
-                    float4 const* tp = S.leafTris + 4 * static_cast<size_t>(first + j);
-                    float4 const a = tp[0], b = tp[1], e = tp[2];
-                    V3 const n = mk(a.x, a.y, a.z), v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x),
-                             e12 = mk(e.y, e.z, e.w);
-                    // lineTrisIntersection, src/geometry.hpp:117-132 (one lane of the 8-wide form).
-                    float const negDet = dotF(n, d);
-                    bool const detOk = FRONT_ONLY ? (negDet <= -1e-6f) : (fabsf(negDet) >= 1e-6f);
-                    if (!detOk) continue;
-                    float const invDet = -1.0f / negDet;
-                    V3 const AO = o - v1;
-                    float const t = dotF(AO, n) * invDet;
-                    V3 const DAO = crossF(AO, d);
-                    float const u = dotF(e13, DAO) * invDet;
-                    float const v = (0.0f - dotF(e12, DAO)) * invDet;
-                    if (!(u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f)) continue;
-                    if (!(t < best.t && t >= tMin)) continue;                // src/bsp.hpp:79
-                    V3 const p = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
-                    bool const inBox = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z
-                                    && p.z <= hi.z;
-                    if (inBox) { best.t = t; best.u = u; best.v = v; best.ref = first + j; has = true; }
-                }
-                if (has) break;                                             // src/bsp.hpp:136-138
+            cur = sp > 0 ? stack[--sp] : NONE;                              // what follows this node
+            if (meets && index < 0) {
+                leafFirst = static_cast<uint32_t>(-(index + 1));
+                leafCount = aux;
+                break;
             }
         }
-        if (sp == 0) break;
-        cur = stack[--sp];
+
+        // ---- phase 2: the leaf's triangles, src/bsp.hpp:58-104 -------------------------------------
+        bool has = false;
+        if (leafCount != 0) {
+            if (COUNT) { c.leafVisits++; c.trisTested += leafCount; }
+            for (uint32_t j = 0; j < leafCount; ++j) {
+                float4 const* tp = S.leafTris + 4 * static_cast<size_t>(leafFirst + j);
+                float4 const a = tp[0], b = tp[1], e = tp[2];
+                V3 const nrm = mk(a.x, a.y, a.z), v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x),
+                         e12 = mk(e.y, e.z, e.w);
+                // lineTrisIntersection, src/geometry.hpp:117-132 (one lane of the 8-wide form).
+                float const negDet = dotF(nrm, d);
+                bool const detOk = FRONT_ONLY ? (negDet <= -1e-6f) : (fabsf(negDet) >= 1e-6f);
+                if (!detOk) continue;
+                V3 const AO = o - v1;
+                V3 const DAO = crossF(AO, d);
+                float const du = dotF(e13, DAO);
+                float const dv = dotF(e12, DAO);
+                if (FRONT_ONLY) {
+                    // u = du*invDet and v = (0-dv)*invDet with 0 < invDet = 1/|negDet|.  A negative
+                    // numerator gives a negative product unless the product underflows to -0; with
+                    // |numerator| > 2^-60 and |negDet| < 2^60 it cannot, so the sign decides without
+                    // the division.
+                    if ((du < -0x1p-60f || dv > 0x1p-60f) && negDet > -0x1p60f) continue;
+                }
+                float const invDet = -1.0f / negDet;
+                float const u = du * invDet;
+                float const v = (0.0f - dv) * invDet;
+                if (!(u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f)) continue;
+                float const t = dotF(AO, nrm) * invDet;
+                if (!(t < best.t && t >= tMin)) continue;                   // src/bsp.hpp:79
+                V3 const p = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+                bool const inBox = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z
+                                && p.z <= hi.z;
+                if (inBox) { best.t = t; best.u = u; best.v = v; best.ref = leafFirst + j; has = true; }
+            }
+        }
+        // First leaf with an accepted hit ends the search (src/bsp.hpp:136-138); so does running out of nodes.
+        if (has || cur == NONE) {
+            store(line, best, o, d);
+            active = false;
+        }
     }
-    return best;
 }
 
 // Philox-4x32-10 keyed by the render seed; counter = (pixel index, sample index, dimension pair, 0).
@@ -244,28 +345,31 @@ __device__ __forceinline__ void flushCounters(const Counters& c, Counters* g) {
 // rt_intersect: one lane per line.
 template <bool FRONT_ONLY>
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DevScene S, const float* __restrict__ origins,
-                                                        const float* __restrict__ directions, uint64_t n,
-                                                        float tMin, rt_hit* __restrict__ out) {
-    uint64_t const stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+                                                        const float* __restrict__ directions, uint32_t n,
+                                                        float tMin, rt_hit* __restrict__ out,
+                                                        uint32_t* __restrict__ nextLine) {
     Counters c = {};
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-        V3 const o = mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
-        V3 const d = mk(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]);
-        HitRec const h = closestHit<FRONT_ONLY, false>(S, o, d, tMin, c);
-        rt_hit r;
-        if (h.ref != 0xFFFFFFFFu) {
-            float4 const ids = S.leafTris[4 * static_cast<size_t>(h.ref) + 3];
-            r.t = h.t; r.u = h.u; r.v = h.v;
-            r.point[0] = o.x + h.t * d.x; r.point[1] = o.y + h.t * d.y; r.point[2] = o.z + h.t * d.z;
-            r.mesh = __float_as_uint(ids.x); r.tri = __float_as_uint(ids.y);
-        }
-        else {
-            r.t = 0.0f; r.u = 0.0f; r.v = 0.0f;
-            r.point[0] = r.point[1] = r.point[2] = 0.0f;
-            r.mesh = 0xFFFFFFFFu; r.tri = 0xFFFFFFFFu;
-        }
-        out[i] = r;
-    }
+    traceStream<FRONT_ONLY, false>(
+        S, n, nextLine, tMin, c,
+        [&](uint32_t i, V3& o, V3& d) {
+            o = mk(origins[3 * static_cast<size_t>(i)], origins[3 * static_cast<size_t>(i) + 1], origins[3 * static_cast<size_t>(i) + 2]);
+            d = mk(directions[3 * static_cast<size_t>(i)], directions[3 * static_cast<size_t>(i) + 1], directions[3 * static_cast<size_t>(i) + 2]);
+        },
+        [&](uint32_t i, HitRec const& h, V3 o, V3 d) {
+            rt_hit r;
+            if (h.ref != 0xFFFFFFFFu) {
+                float4 const ids = S.leafTris[4 * static_cast<size_t>(h.ref) + 3];
+                r.t = h.t; r.u = h.u; r.v = h.v;
+                r.point[0] = o.x + h.t * d.x; r.point[1] = o.y + h.t * d.y; r.point[2] = o.z + h.t * d.z;
+                r.mesh = __float_as_uint(ids.x); r.tri = __float_as_uint(ids.y);
+            }
+            else {
+                r.t = 0.0f; r.u = 0.0f; r.v = 0.0f;
+                r.point[0] = r.point[1] = r.point[2] = 0.0f;
+                r.mesh = 0xFFFFFFFFu; r.tri = 0xFFFFFFFFu;
+            }
+            out[i] = r;
+        });
 }
 
 // Path state, structure of arrays over the batch's path slots (slot = sampleInBatch * pixels + pixel):
@@ -302,19 +406,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P,
 }
 
 // One closest-hit query per live path.  `bounce` selects the input queue; bounce 0 is the identity.
+// counts[RT_FETCH_BASE + bounce] is this launch's line-fetch cursor (zeroed with the counts).
+#define RT_FETCH_BASE 512u
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, PathState P, uint32_t bounce, float tMin,
                                                     Counters* __restrict__ gc) {
     uint32_t const n = P.counts[bounce];
     uint32_t const* __restrict__ q = P.queue[bounce & 1];
-    uint32_t const stride = gridDim.x * blockDim.x;
     Counters c = {};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint32_t const slot = bounce == 0 ? i : q[i];
-        float4 const A = P.A[slot], B = P.B[slot];
-        HitRec const h = closestHit<true, COUNT>(S, mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), tMin, c);
-        P.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.ref));
-    }
+    traceStream<true, COUNT>(
+        S, n, P.counts + RT_FETCH_BASE + bounce, tMin, c,
+        [&](uint32_t i, V3& o, V3& d) {
+            uint32_t const slot = bounce == 0 ? i : q[i];
+            float4 const A = P.A[slot], B = P.B[slot];
+            o = mk(A.x, A.y, A.z);
+            d = mk(A.w, B.x, B.y);
+        },
+        [&](uint32_t i, HitRec const& h, V3, V3) {
+            uint32_t const slot = bounce == 0 ? i : q[i];
+            P.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.ref));
+        });
     if (COUNT) flushCounters(c, gc);
 }
 
@@ -491,6 +602,7 @@ __global__ void k_selftest(int op, const float* __restrict__ a, const float* __r
     }
     case 4: out[i] = __fmaf_rn(a[i], b[i], a[i]); break;
     case 5: out[i] = a[i] * b[i] + a[i]; break;          // must NOT be fused
+    case 6: out[i] = divByRecip(a[i], b[i], 1.0f / b[i]); break;
     default: out[i] = 0.0f;
     }
 }
@@ -618,6 +730,13 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
             todo.push_back({pair, in.neg_index, it.depth + 1});
         }
     }
+    bool fastDivision = true;
+    for (HNode const& n : nodes)
+        for (int k = 0; k < 3; ++k)
+            for (float c : {n.lo[k], n.hi[k]}) {
+                float const a = std::fabs(c);
+                if (!(a == 0.0f || (a >= 0x1p-75f && a < 0x1p100f))) fastDivision = false;
+            }
     if (maxDepth > RT_STACK_MAX)
         return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth " + std::to_string(maxDepth) + " exceeds the "
                     + std::to_string(RT_STACK_MAX) + "-entry traversal stack");
@@ -679,7 +798,7 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     if (e == hipSuccess) e = upload(&s->dTriNormals, triNormals.data(), triNormals.size() * 4);
     if (e == hipSuccess) e = upload(&s->dMaterials, mats.data(), matBytes);
     if (e == hipSuccess) e = hipMalloc(&s->wsCounts, 4096);
-    if (e == hipSuccess) e = hipMalloc(&s->wsCounters, sizeof(Counters));
+    if (e == hipSuccess) e = hipMalloc(&s->wsCounters, 1024);
     if (e != hipSuccess) {
         rt_scene_destroy(s);
         return fail(RT_ERR_HIP, std::string("rt_scene_create: upload failed: ") + hipGetErrorString(e));
@@ -688,6 +807,7 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     s->dev.leafTris = static_cast<const float4*>(s->dLeafTris);
     s->dev.triNormals = static_cast<const float4*>(s->dTriNormals);
     s->dev.materials = static_cast<const float4*>(s->dMaterials);
+    s->dev.fastDivision = fastDivision ? 1 : 0;
     s->nodeCount = static_cast<uint32_t>(nodes.size());
     s->leafTriCount = refCount;
     s->depth = maxDepth;
@@ -721,9 +841,16 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t const st = static_cast<hipStream_t>(hip_stream);
-    int const grid = gridFor(s, n);
-    if (front_only) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins, d_directions, n, t_min, d_out);
-    else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins, d_directions, n, t_min, d_out);
+    // The kernel hands out lines through a 32-bit cursor: larger batches go in slices.
+    uint64_t const slice = 0xF0000000ull;
+    for (uint64_t done = 0; done < n; done += slice) {
+        uint32_t const m = static_cast<uint32_t>(std::min<uint64_t>(slice, n - done));
+        uint32_t* cursor = static_cast<uint32_t*>(s->wsCounters) + 64;     // behind the Counters block
+        HIP_TRY(hipMemsetAsync(cursor, 0, 4, st));
+        int const grid = gridFor(s, m);
+        if (front_only) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins + 3 * done, d_directions + 3 * done, m, t_min, d_out + done, cursor);
+        else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins + 3 * done, d_directions + 3 * done, m, t_min, d_out + done, cursor);
+    }
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -761,7 +888,7 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
         return fail(RT_ERR_INVALID, "rt_render: rectangle outside the image");
     if (static_cast<uint64_t>(p->width) * p->height > 0xFFFFFFFFull)
         return fail(RT_ERR_LIMIT, "rt_render: more than 2^32 pixels");
-    if (p->bounce_limit > 1000) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit above 1000");
+    if (p->bounce_limit > 500) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit above 500");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t const st = static_cast<hipStream_t>(hip_stream);
     auto const t0 = std::chrono::steady_clock::now();
@@ -786,7 +913,7 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
         s->wsPixels = pixels;
     }
     uint32_t const bounceCount = p->bounce_limit + 1;      // intersections per path, src/render.hpp:88
-    if ((bounceCount + 2) * 4 > 4096) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit too large");
+    if (bounceCount + 2 > RT_FETCH_BASE) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit too large");
 
     PathState P;
     P.A = static_cast<float4*>(s->wsA); P.B = static_cast<float4*>(s->wsB); P.C = static_cast<float4*>(s->wsC);
@@ -822,7 +949,7 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
         uint32_t const nb = std::min(spb, p->spp - done);
         uint32_t const paths = static_cast<uint32_t>(pixels * nb);
         int const grid = gridFor(s, paths);
-        HIP_TRY(hipMemsetAsync(P.counts, 0, (bounceCount + 2) * 4, st));
+        HIP_TRY(hipMemsetAsync(P.counts, 0, 4096, st));
         mark(0);
         hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, R, P, static_cast<uint32_t>(pixels), done, paths);
         mark(-1);
