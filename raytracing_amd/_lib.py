@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIB selects another build of the same library (e.g. the diagnostic build with phase stamps).
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 c_u32, c_u64, c_i32, c_f32, c_int = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32, ctypes.c_float, ctypes.c_int
 vp = ctypes.c_void_p

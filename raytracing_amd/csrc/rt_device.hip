@@ -20,6 +20,7 @@
 
 #define RT_STACK_MAX 64          // per-lane traversal stack entries (tree depth bound)
 #define RT_BLOCK 256
+#define RT_LDS_STACK_DEPTH 16   // trees at most this deep keep the traversal stack in LDS (16 KiB per block)
 
 namespace {
 
@@ -162,13 +163,19 @@ struct HitRec {
 //   load(i, o, d)        reads line i of the stream
 //   store(i, hit, o, d)  receives its nearest hit (hit.ref == 0xFFFFFFFF: none)
 #define RT_FETCH_CHUNK 256u
-template <bool FRONT_ONLY, bool COUNT, class Load, class Store>
+template <bool FRONT_ONLY, bool COUNT, int LDS_STACK, class Load, class Store>
 __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint32_t* __restrict__ nextLine, float tMin,
                                             Counters& c, Load load, Store store) {
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t const lane = threadIdx.x & 63u;
     unsigned long long const below = (1ull << lane) - 1ull;
-    uint32_t stack[RT_STACK_MAX];
+    // The stack of deferred far children lives in LDS, one column per lane (entry i of lane l at
+    // [i][l]: conflict-free), when the tree is shallow enough for LDS_STACK entries; otherwise in
+    // scratch memory.
+    __shared__ uint32_t ldsStack[(LDS_STACK > 0 ? LDS_STACK : 1) * RT_BLOCK];
+    uint32_t scratchStack[LDS_STACK > 0 ? 1 : RT_STACK_MAX];
+    uint32_t* const stack = LDS_STACK > 0 ? ldsStack + threadIdx.x : scratchStack;
+    constexpr int STRIDE = LDS_STACK > 0 ? RT_BLOCK : 1;
     // wave-uniform fetch state
     uint32_t chunkNext = 0, chunkEnd = 0;
     bool drained = false;
@@ -229,11 +236,11 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 float const plane = (la + ha) / 2.0f;
                 bool const positiveNear = (oa - plane) >= 0.0f;            // src/bsp.hpp:133
                 uint32_t const base = static_cast<uint32_t>(index);
-                stack[sp++] = positiveNear ? base : base + 1;               // far child
+                stack[(sp++) * STRIDE] = positiveNear ? base : base + 1;    // far child
                 cur = positiveNear ? base + 1 : base;                       // near child
                 continue;
             }
-            cur = sp > 0 ? stack[--sp] : NONE;                              // what follows this node
+            cur = sp > 0 ? stack[(--sp) * STRIDE] : NONE;                   // what follows this node
             if (meets && index < 0) {
                 leafFirst = static_cast<uint32_t>(-(index + 1));
                 leafCount = aux;
@@ -343,13 +350,13 @@ __device__ __forceinline__ void flushCounters(const Counters& c, Counters* g) {
 }
 
 // rt_intersect: one lane per line.
-template <bool FRONT_ONLY>
+template <bool FRONT_ONLY, int LDS_STACK>
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DevScene S, const float* __restrict__ origins,
                                                         const float* __restrict__ directions, uint32_t n,
                                                         float tMin, rt_hit* __restrict__ out,
                                                         uint32_t* __restrict__ nextLine) {
     Counters c = {};
-    traceStream<FRONT_ONLY, false>(
+    traceStream<FRONT_ONLY, false, LDS_STACK>(
         S, n, nextLine, tMin, c,
         [&](uint32_t i, V3& o, V3& d) {
             o = mk(origins[3 * static_cast<size_t>(i)], origins[3 * static_cast<size_t>(i) + 1], origins[3 * static_cast<size_t>(i) + 2]);
@@ -408,13 +415,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P,
 // One closest-hit query per live path.  `bounce` selects the input queue; bounce 0 is the identity.
 // counts[RT_FETCH_BASE + bounce] is this launch's line-fetch cursor (zeroed with the counts).
 #define RT_FETCH_BASE 512u
-template <bool COUNT>
+template <bool COUNT, int LDS_STACK>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, PathState P, uint32_t bounce, float tMin,
                                                     Counters* __restrict__ gc) {
     uint32_t const n = P.counts[bounce];
     uint32_t const* __restrict__ q = P.queue[bounce & 1];
     Counters c = {};
-    traceStream<true, COUNT>(
+    traceStream<true, COUNT, LDS_STACK>(
         S, n, P.counts + RT_FETCH_BASE + bounce, tMin, c,
         [&](uint32_t i, V3& o, V3& d) {
             uint32_t const slot = bounce == 0 ? i : q[i];
@@ -848,8 +855,13 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
         uint32_t* cursor = static_cast<uint32_t*>(s->wsCounters) + 64;     // behind the Counters block
         HIP_TRY(hipMemsetAsync(cursor, 0, 4, st));
         int const grid = gridFor(s, m);
-        if (front_only) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins + 3 * done, d_directions + 3 * done, m, t_min, d_out + done, cursor);
-        else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins + 3 * done, d_directions + 3 * done, m, t_min, d_out + done, cursor);
+#define RT_LAUNCH_INTERSECT(FRONT, STACK)                                                                     \
+    hipLaunchKernelGGL((k_intersect<FRONT, STACK>), dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins + 3 * done, \
+                       d_directions + 3 * done, m, t_min, d_out + done, cursor)
+        bool const lds = s->depth <= RT_LDS_STACK_DEPTH;
+        if (front_only) { if (lds) RT_LAUNCH_INTERSECT(true, RT_LDS_STACK_DEPTH); else RT_LAUNCH_INTERSECT(true, 0); }
+        else { if (lds) RT_LAUNCH_INTERSECT(false, RT_LDS_STACK_DEPTH); else RT_LAUNCH_INTERSECT(false, 0); }
+#undef RT_LAUNCH_INTERSECT
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -955,8 +967,12 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
         mark(-1);
         for (uint32_t b = 0; b < bounceCount; ++b) {
             mark(1);
-            if (countWork) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc);
-            else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc);
+#define RT_LAUNCH_TRACE(COUNT, STACK) \
+    hipLaunchKernelGGL((k_trace<COUNT, STACK>), dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc)
+            bool const lds = s->depth <= RT_LDS_STACK_DEPTH;
+            if (countWork) { if (lds) RT_LAUNCH_TRACE(true, RT_LDS_STACK_DEPTH); else RT_LAUNCH_TRACE(true, 0); }
+            else { if (lds) RT_LAUNCH_TRACE(false, RT_LDS_STACK_DEPTH); else RT_LAUNCH_TRACE(false, 0); }
+#undef RT_LAUNCH_TRACE
             mark(-1);
             mark(2);
             hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, R, P, b, done, static_cast<uint32_t>(pixels), gc);
