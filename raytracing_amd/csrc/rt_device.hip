@@ -162,7 +162,7 @@ struct HitRec {
 // their rank among the idle lanes.
 //   load(i, o, d)        reads line i of the stream
 //   store(i, hit, o, d)  receives its nearest hit (hit.ref == 0xFFFFFFFF: none)
-#define RT_FETCH_CHUNK 256u
+#define RT_FETCH_CHUNK 64u
 template <bool FRONT_ONLY, bool COUNT, int LDS_STACK, class Load, class Store>
 __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint32_t* __restrict__ nextLine, float tMin,
                                             Counters& c, Load load, Store store) {
@@ -254,13 +254,17 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             if (COUNT) { c.leafVisits++; c.trisTested += leafCount; }
             for (uint32_t j = 0; j < leafCount; ++j) {
                 float4 const* tp = S.leafTris + 4 * static_cast<size_t>(leafFirst + j);
-                float4 const a = tp[0], b = tp[1], e = tp[2];
-                V3 const nrm = mk(a.x, a.y, a.z), v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x),
-                         e12 = mk(e.y, e.z, e.w);
-                // lineTrisIntersection, src/geometry.hpp:117-132 (one lane of the 8-wide form).
+                // lineTrisIntersection, src/geometry.hpp:117-132 (one lane of the 8-wide form).  The
+                // facing test needs only the first 16 bytes of the record; lanes that fail it do not
+                // fetch the rest (scattered 16-byte loads are what this kernel is bound by).
+                float4 a = tp[0];
+                asm volatile("" : "+v"(a.w));       // keep the first fetch one 16-byte load
+                V3 const nrm = mk(a.x, a.y, a.z);
                 float const negDet = dotF(nrm, d);
                 bool const detOk = FRONT_ONLY ? (negDet <= -1e-6f) : (fabsf(negDet) >= 1e-6f);
                 if (!detOk) continue;
+                float4 const b = tp[1], e = tp[2];
+                V3 const v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x), e12 = mk(e.y, e.z, e.w);
                 V3 const AO = o - v1;
                 V3 const DAO = crossF(AO, d);
                 float const du = dotF(e13, DAO);
