@@ -20,6 +20,7 @@
 
 #define RT_STACK_MAX 64          // per-lane traversal stack entries (tree depth bound)
 #define RT_BLOCK 256
+#define RT_STAGE 256u                // survivors staged per wave before one append to the next queue
 #define RT_LDS_STACK_DEPTH 16   // trees at most this deep keep the traversal stack in LDS (16 KiB per block)
 
 namespace {
@@ -452,6 +453,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
     uint32_t const lane = threadIdx.x & 63;
     uint32_t const stride = gridDim.x * blockDim.x;
     uint32_t shaded = 0;
+    __shared__ uint32_t stageAll[(RT_BLOCK / 64) * RT_STAGE];
+    volatile uint32_t* const stage = stageAll + (threadIdx.x >> 6) * RT_STAGE;   // this wave's staging area
+    uint32_t staged = 0;                                                          // wave-uniform
     // The loop bound is wave-uniform so that every lane reaches the ballot.
     uint32_t const first = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
     for (uint32_t base = first; base < n; base += stride) {
@@ -545,18 +549,28 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
                 P.C[slot] = C;
             }
         }
-        // Stream compaction: ballot, prefix count below the lane, one atomic per wave.
+        // Stream compaction: ballot, prefix count below the lane.  Survivors are staged in LDS per wave
+        // and appended to the next queue in runs of up to 256 with one atomic per run: atomics on the
+        // single queue counter serialise (a few ns each), one per 64 paths was a quarter of this kernel.
         unsigned long long const mask = __ballot(alive);
-        if (mask != 0ull) {
-            uint32_t const cnt = static_cast<uint32_t>(__popcll(mask));
-            uint32_t start = 0;
-            if (lane == 0) start = atomicAdd(&P.counts[bounce + 1], cnt);
-            start = __shfl(start, 0, 64);
-            if (alive) {
-                uint32_t const rank = static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-                qout[start + rank] = slot;
-            }
+        if (alive) {
+            uint32_t const rank = static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+            stage[staged + rank] = slot;
         }
+        staged += static_cast<uint32_t>(__popcll(mask));
+        if (staged > RT_STAGE - 64u) {
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(&P.counts[bounce + 1], staged);
+            start = __builtin_amdgcn_readfirstlane(start);
+            for (uint32_t k = lane; k < staged; k += 64) qout[start + k] = stage[k];
+            staged = 0;
+        }
+    }
+    if (staged != 0u) {
+        uint32_t start = 0;
+        if (lane == 0) start = atomicAdd(&P.counts[bounce + 1], staged);
+        start = __builtin_amdgcn_readfirstlane(start);
+        for (uint32_t k = lane; k < staged; k += 64) qout[start + k] = stage[k];
     }
     unsigned long long const s = waveSum(shaded);
     if (lane == 0 && s) atomicAdd(&gc->shadedHits, s);
