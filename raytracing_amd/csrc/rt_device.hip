@@ -177,7 +177,15 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     uint32_t scratchStack[LDS_STACK > 0 ? 1 : RT_STACK_MAX];
     uint32_t* const stack = LDS_STACK > 0 ? ldsStack + threadIdx.x : scratchStack;
     constexpr int STRIDE = LDS_STACK > 0 ? RT_BLOCK : 1;
-    // wave-uniform fetch state
+    // wave-uniform fetch state.  The first three quarters of the stream are dealt out statically, chunk
+    // c to wave c mod waves (concurrent waves then work on neighbouring chunks, which keeps the caches
+    // warm, and no atomic is needed); the rest is handed out through the cursor so that no wave is left
+    // holding a long tail.  An atomic on the one cursor costs several ns because they serialise.
+    uint32_t const waves = gridDim.x * (RT_BLOCK / 64u);
+    uint32_t const waveId = blockIdx.x * (RT_BLOCK / 64u) + (threadIdx.x >> 6);
+    uint32_t const staticRounds = static_cast<uint32_t>((static_cast<uint64_t>(n) * 3u / 4u) / (static_cast<uint64_t>(waves) * RT_FETCH_CHUNK));
+    uint32_t const staticLines = staticRounds * waves * RT_FETCH_CHUNK;
+    uint32_t staticRound = 0;
     uint32_t chunkNext = 0, chunkEnd = 0;
     bool drained = false;
     // per-lane line state
@@ -195,8 +203,14 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
         while (idle != 0ull && !drained) {
             if (chunkNext == chunkEnd) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(nextLine, RT_FETCH_CHUNK);
-                base = __builtin_amdgcn_readfirstlane(base);
+                if (staticRound < staticRounds) {
+                    base = (staticRound * waves + waveId) * RT_FETCH_CHUNK;
+                    ++staticRound;
+                }
+                else {
+                    if (lane == 0) base = atomicAdd(nextLine, RT_FETCH_CHUNK);
+                    base = staticLines + __builtin_amdgcn_readfirstlane(base);
+                }
                 if (base >= n) { drained = true; break; }
                 chunkNext = base;
                 chunkEnd = min(base + RT_FETCH_CHUNK, n);
