@@ -338,13 +338,13 @@ static bsp_node create_node(orc_scene* s, box3 box, int axis, int depth) {
     return node;
 }
 
-orc_scene* orc_scene_create(const float* positions, const float* normals, uint32_t vertexCount,
-                            const uint32_t* tris, uint32_t triCount,
-                            const uint32_t* meshVertexRanges, const uint32_t* meshTriRanges, uint32_t meshCount,
-                            const float* materials, uint32_t materialCount,
-                            const float* transforms, const uint32_t* modelMeshes, const uint32_t* modelMaterials,
-                            uint32_t modelCount, const float* camera, uint32_t width, uint32_t height,
-                            int inflateMode) {
+static orc_scene* scene_prepare(const float* positions, const float* normals, uint32_t vertexCount,
+                                const uint32_t* tris, uint32_t triCount,
+                                const uint32_t* meshVertexRanges, const uint32_t* meshTriRanges, uint32_t meshCount,
+                                const float* materials, uint32_t materialCount,
+                                const float* transforms, const uint32_t* modelMeshes, const uint32_t* modelMaterials,
+                                uint32_t modelCount, const float* camera, uint32_t width, uint32_t height,
+                                int inflateMode) {
     orc_scene* s = (orc_scene*)calloc(1, sizeof(orc_scene));
     s->modelCount = modelCount; s->baseVertexCount = vertexCount; s->baseTriCount = triCount;
     s->meshCount = meshCount; s->materialCount = materialCount; s->width = width; s->height = height;
@@ -440,8 +440,58 @@ orc_scene* orc_scene_create(const float* positions, const float* normals, uint32
         bb.min = sub3(bb.min, V(pad, pad, pad)); bb.max = add3(bb.max, V(pad, pad, pad));
     }
     s->rootBox = bb;
-    s->root = create_node(s, bb, 0, 0);
+    return s;
+}
+
+orc_scene* orc_scene_create(const float* positions, const float* normals, uint32_t vertexCount,
+                            const uint32_t* tris, uint32_t triCount,
+                            const uint32_t* meshVertexRanges, const uint32_t* meshTriRanges, uint32_t meshCount,
+                            const float* materials, uint32_t materialCount,
+                            const float* transforms, const uint32_t* modelMeshes, const uint32_t* modelMaterials,
+                            uint32_t modelCount, const float* camera, uint32_t width, uint32_t height,
+                            int inflateMode) {
+    orc_scene* s = scene_prepare(positions, normals, vertexCount, tris, triCount, meshVertexRanges, meshTriRanges,
+                                 meshCount, materials, materialCount, transforms, modelMeshes, modelMaterials,
+                                 modelCount, camera, width, height, inflateMode);
+    s->root = create_node(s, s->rootBox, 0, 0);
     if (s->buildFailed) { orc_scene_destroy(s); return NULL; }
+    return s;
+}
+
+orc_scene* orc_scene_create_with_tree(const float* positions, const float* normals, uint32_t vertexCount,
+                                      const uint32_t* tris, uint32_t triCount,
+                                      const uint32_t* meshVertexRanges, const uint32_t* meshTriRanges, uint32_t meshCount,
+                                      const float* materials, uint32_t materialCount,
+                                      const float* transforms, const uint32_t* modelMeshes,
+                                      const uint32_t* modelMaterials, uint32_t modelCount, const float* camera,
+                                      uint32_t width, uint32_t height, int inflateMode,
+                                      int32_t rootIndex, const void* inodes60, uint32_t inodeCount,
+                                      const uint32_t* leafFirstRef, const uint32_t* leafRefs, uint32_t leafCount) {
+    orc_scene* s = scene_prepare(positions, normals, vertexCount, tris, triCount, meshVertexRanges, meshTriRanges,
+                                 meshCount, materials, materialCount, transforms, modelMeshes, modelMaterials,
+                                 modelCount, camera, width, height, inflateMode);
+    s->root.box = s->rootBox;
+    s->root.index = rootIndex;
+    s->inodes = (bsp_inode*)calloc(inodeCount ? inodeCount : 1, sizeof(bsp_inode));
+    s->inodeCount = s->inodeCap = inodeCount;
+    for (uint32_t i = 0; i < inodeCount; ++i) {
+        const unsigned char* rec = (const unsigned char*)inodes60 + 60 * (size_t)i;   /* src/bsp.hpp:148-159 layout */
+        memcpy(&s->inodes[i].neg.box, rec, 24); memcpy(&s->inodes[i].neg.index, rec + 24, 4);
+        memcpy(&s->inodes[i].pos.box, rec + 28, 24); memcpy(&s->inodes[i].pos.index, rec + 52, 4);
+        s->inodes[i].axis = rec[56];
+    }
+    s->leaves = (bsp_leaf*)calloc(leafCount ? leafCount : 1, sizeof(bsp_leaf));
+    s->leafCount = s->leafCap = leafCount;
+    for (uint32_t l = 0; l < leafCount; ++l) {
+        uint32_t n = leafFirstRef[l + 1] - leafFirstRef[l];
+        if (n > 32) { orc_scene_destroy(s); return NULL; }              /* Leaf::MAX_TRIS, src/bsp.hpp:162 */
+        s->leaves[l].count = (uint8_t)n;
+        for (uint32_t k = 0; k < n; ++k) {
+            uint32_t mesh = leafRefs[2 * (size_t)(leafFirstRef[l] + k)], tri = leafRefs[2 * (size_t)(leafFirstRef[l] + k) + 1];
+            s->leaves[l].mesh[k] = mesh; s->leaves[l].tri[k] = tri;
+            s->leaves[l].tris[k] = s->pretris[s->triRanges[2 * mesh] + tri];
+        }
+    }
     return s;
 }
 

@@ -54,6 +54,18 @@ orc_scene* orc_scene_create(const float* positions, const float* normals, uint32
                             const float* transforms, const uint32_t* modelMeshes, const uint32_t* modelMaterials,
                             uint32_t modelCount, const float* camera, uint32_t width, uint32_t height,
                             int inflateMode);
+/* Same preprocessing, but with a tree supplied by the caller (interior nodes in the 60-byte layout of
+ * BSPTree::INode, src/bsp.hpp:148-159; leaf triangle references as {model, tri} pairs): lets the oracle
+ * traverse trees far too large for the reference's O(nodes x triangles) build.  NULL if a leaf exceeds 32. */
+orc_scene* orc_scene_create_with_tree(const float* positions, const float* normals, uint32_t vertexCount,
+                                      const uint32_t* tris, uint32_t triCount,
+                                      const uint32_t* meshVertexRanges, const uint32_t* meshTriRanges, uint32_t meshCount,
+                                      const float* materials, uint32_t materialCount,
+                                      const float* transforms, const uint32_t* modelMeshes,
+                                      const uint32_t* modelMaterials, uint32_t modelCount, const float* camera,
+                                      uint32_t width, uint32_t height, int inflateMode,
+                                      int32_t rootIndex, const void* inodes60, uint32_t inodeCount,
+                                      const uint32_t* leafFirstRef, const uint32_t* leafRefs, uint32_t leafCount);
 void orc_scene_destroy(orc_scene*);
 
 /* counts: [0] models [1] instantiated vertices [2] preprocessed tris [3] inodes [4] leaves

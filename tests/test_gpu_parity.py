@@ -353,3 +353,48 @@ def test_full_hd_properties(builtin):
     assert sa["segments"] + sb["segments"] == st["segments"]
     assert st["paths"] == w * h * 2 and st["paths"] < st["segments"] <= 9 * st["paths"]
     assert np.isfinite(full).all() and (full >= 0).all()
+
+
+def test_dragon_scale_scene_full_size(oracle_lib):
+    """BASELINE config 3: about 0.9 M triangles.  The reference's own tree build is O(nodes x triangles)
+    and cannot produce this tree in any reasonable time, so the oracle traverses the tree made by the
+    product's builder (whose equality with the reference algorithm is established on small scenes in
+    tests/test_host.py); hits and a rendered tile must still agree bit for bit, and the frame must not
+    depend on how it is tiled."""
+    sc = scenes.dragon_scale_scene(900_000).preprocess()
+    assert 850_000 < len(sc.preprocessed_tris.tris) < 950_000 and sc.bsp_tree.oversized_leaves == 0
+    ds = DeviceScene(RayTraceData(sc))
+    w, h = 1920, 1080
+    osc = oracle_lib.scene_create_with_tree(base_from_scene(sc), w, h, sc.bsp_tree)
+    try:
+        assert ds.depth > 16                       # exercises the scratch-memory traversal stack
+        # 60 000 primary rays on a pixel grid + 60 000 secondary-style rays from inside the scene box
+        ys, xs = np.mgrid[0:h:6, 0:w:6]
+        xy = np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], 1).astype(np.float32)[:60_000]
+        d0 = osc.camera_rays(xy)
+        o0 = np.tile(sc.camera.position, (len(xy), 1)).astype(np.float32)
+        f, ids = osc.intersect(o0, d0)
+        _check_hits(ds.intersect(o0, d0), f, ids)
+        assert (ids[:, 0] != 0xFFFFFFFF).mean() > 0.5
+        rng = np.random.default_rng(4)
+        o1 = (f[:, 3:6] + rng.uniform(-0.3, 0.3, (len(f), 3))).astype(np.float32)
+        d1 = rng.standard_normal((len(f), 3))
+        d1 = (d1 / np.linalg.norm(d1, axis=1, keepdims=True)).astype(np.float32)
+        for front in (True, False):
+            f1, ids1 = osc.intersect(o1, d1, 1e-3, front)
+            _check_hits(ds.intersect(o1, d1, 1e-3, front), f1, ids1)
+        # a 96x64 tile in the middle of the frame, 2 spp, against the oracle
+        rect = (900, 500, 96, 64)
+        p2r = sc.pixel_to_ray_transform(w, h)
+        tile, st = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=2, rect=rect, flags=_lib.RT_FLAG_COUNT_WORK))
+        otile, ost = osc.render_device_mode(osc.render_params(2, rect=rect), threads=16)
+        _assert_same_image_and_work(tile, st, otile, ost)
+        # full frame at 1 spp: deterministic, and equal to the same frame rendered as two halves
+        full, sf = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1))
+        left, sl = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, rect=(0, 0, 1000, h)))
+        right, sr = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, rect=(1000, 0, w - 1000, h)))
+        assert same_bits(np.concatenate([left, right], axis=1), full)
+        assert sl["segments"] + sr["segments"] == sf["segments"]
+        assert np.isfinite(full).all() and full.max() > 0
+    finally:
+        ds.close(); osc.close()

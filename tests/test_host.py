@@ -134,3 +134,27 @@ def test_material_and_colour_helpers():
     L = _lib.lib()
     for v in (0.0, 0.02, 0.04045, 0.2, 0.5, 1.0):
         assert abs(L.rt_linear_to_srgb(L.rt_srgb_to_linear(v)) - v) < 1e-6
+
+
+def test_oracle_traverses_supplied_tree_like_its_own(oracle_lib):
+    """orc_scene_create_with_tree (used for scenes too large for the reference's tree build) gives the
+    same hits and radiance as the oracle's own reference-faithful build of the same scene."""
+    sc = scenes.cornell_scene(wall_grid=8, box_grid=3).preprocess()
+    base = base_from_scene(sc)
+    own = oracle_lib.scene_create(base, 48, 32)
+    given = oracle_lib.scene_create_with_tree(base, 48, 32, sc.bsp_tree)
+    try:
+        a, b = own.bsp(), given.bsp()
+        for k in a:
+            assert same_bits(a[k], b[k]), k
+        rng = np.random.default_rng(11)
+        o = rng.uniform(-4.5, 4.5, (4000, 3)).astype(np.float32) + np.array([0, 5, 0], np.float32)
+        d = rng.standard_normal((4000, 3))
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        fa, ia = own.intersect(o, d)
+        fb, ib = given.intersect(o, d)
+        assert same_bits(fa, fb) and np.array_equal(ia, ib)
+        pa, pb = own.render_params(2), given.render_params(2)
+        assert same_bits(own.render_device_mode(pa, threads=4)[0], given.render_device_mode(pb, threads=4)[0])
+    finally:
+        own.close(); given.close()
