@@ -52,7 +52,8 @@ class RtStats(ctypes.Structure):
                 ("tris_tested", c_u64), ("leaf_visits", c_u64), ("inode_visits", c_u64),
                 ("ms_total", ctypes.c_double), ("ms_raygen", ctypes.c_double), ("ms_trace", ctypes.c_double),
                 ("ms_shade", ctypes.c_double), ("ms_accumulate", ctypes.c_double),
-                ("trace_launches", c_u32), ("batches", c_u32)]
+                ("trace_launches", c_u32), ("batches", c_u32),
+                ("box_exact_fallbacks", c_u64), ("box_filter_errors", c_u64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

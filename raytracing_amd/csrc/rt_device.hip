@@ -14,14 +14,16 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #define RT_STACK_MAX 64          // per-lane traversal stack entries (tree depth bound)
 #define RT_BLOCK 256
 #define RT_STAGE 256u                // survivors staged per wave before one append to the next queue
-#define RT_LDS_STACK_DEPTH 16   // trees at most this deep keep the traversal stack in LDS (16 KiB per block)
+#define RT_LDS_STACK_DEPTH 16   // traversal stack entries kept in LDS (16 KiB per block); deeper ones spill to scratch
 
 namespace {
 
@@ -59,10 +61,12 @@ struct DevScene {
     const float4* triNormals;
     const float4* materials;
     int fastDivision;      // every box plane coordinate is 0 or in [2^-75, 2^100): see divByRecip
+    float boxAbsMax;       // largest |coordinate| of the root box: see filterMargin
 };
 
 struct Counters {
     unsigned long long boxTests, trisTested, leafVisits, inodeVisits, shadedHits, segments, paths;
+    unsigned long long boxFallbacks, boxFilterErrors;
 };
 
 struct RenderConst {
@@ -143,6 +147,50 @@ __device__ __forceinline__ bool coordInFastRange(float x) {
     return (a == 0.0f) | ((a >= 0x1p-75f) & (a < 0x1p100f));
 }
 
+// ---- conservative filter in front of the six-face test ---------------------------------------------
+// The six-face test is ~110 VALU operations; most (line, box) pairs are nowhere near its decision
+// boundary.  boxFilter decides those from the slab crossing times T = (plane - origin) * RN(1/direction)
+// (~35 operations) and leaves the rest to the exact test, so the result is always the reference's.
+//
+// Why a sure decision equals the reference's.  The reference evaluates a face of axis a at
+// t~ = RN(RN(numerator)/denominator), which differs from the exact crossing time only by a relative
+// error below 2^-22, and accepts it when p~_b = RN(o_b + RN(t~ d_b)) lies in [lo_b, hi_b] on the two other
+// axes; p~_b differs from the exact position by at most 2^-22 (|p_b| + |o_b|).  With
+// m = 2^-20 (largest |box coordinate| + largest |origin coordinate|), a position at least m inside
+// (outside) the slab is therefore accepted (rejected), i.e. in time units a crossing time at least
+// m |1/d_b| inside (outside) the slab's crossing interval; mu = m max_k |1/d_k| bounds that for every
+// axis.  The T's carry a relative error below 2^-22, covered by the 2^-20 |T| terms.
+//   surely meets:  the exit face (smallest far crossing time tX) has tX > theta, the line is inside the
+//     two other slabs at tX by more than theta (tX - tE > theta and second-smallest far time - tX >
+//     theta), and no direction component is below 2^-16 (else mu = inf): that face's test is true.
+//   surely misses: tX < -theta (on some axis the box lies behind the origin by a margin: every face
+//     either has t < 0 or lies beyond that slab), or tE - tX > 2 mu + 2^-20 (|tE| + |tX|) (every
+//     crossing time is clear of the slab of the latest-entered or of the earliest-left axis).
+// tools/box_filter_check.py replays this arithmetic on the CPU against the exact test; kernels built
+// with COUNT evaluate both on every box and count disagreements (rt_stats.box_filter_errors).
+__device__ __forceinline__ float filterMargin(V3 o, V3 d, V3 r, float boxAbsMax) {
+    float const m = 0x1p-20f * (boxAbsMax + fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)));
+    float const dMin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    float const rMax = fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fabsf(r.z));
+    return dMin >= 0x1p-16f ? m * rMax : INFINITY;
+}
+
+// +1 surely meets, -1 surely misses, 0 undecided.
+__device__ __forceinline__ int boxFilter(V3 o, V3 r, float mu, V3 lo, V3 hi) {
+    float const ax = (lo.x - o.x) * r.x, bx = (hi.x - o.x) * r.x;
+    float const ay = (lo.y - o.y) * r.y, by = (hi.y - o.y) * r.y;
+    float const az = (lo.z - o.z) * r.z, bz = (hi.z - o.z) * r.z;
+    float const tE = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float const xx = fmaxf(ax, bx), xy = fmaxf(ay, by), xz = fmaxf(az, bz);
+    float const tX = fminf(fminf(xx, xy), xz);
+    float const second = __builtin_amdgcn_fmed3f(xx, xy, xz);
+    float const theta = 0x1p-20f * fabsf(tX) + mu;
+    bool const sureHit = (tX - tE > theta) & (second - tX > theta) & (tX > theta);
+    float const theta2 = 0x1p-20f * (fabsf(tE) + fabsf(tX)) + (mu + mu);
+    bool const sureMiss = (tX < -theta) | (tE - tX > theta2);
+    return sureHit ? 1 : (sureMiss ? -1 : 0);
+}
+
 struct HitRec {
     float t, u, v;
     uint32_t ref;       // index of the leaf triangle record, 0xFFFFFFFF = miss
@@ -164,19 +212,18 @@ struct HitRec {
 //   load(i, o, d)        reads line i of the stream
 //   store(i, hit, o, d)  receives its nearest hit (hit.ref == 0xFFFFFFFF: none)
 #define RT_FETCH_CHUNK 64u
-template <bool FRONT_ONLY, bool COUNT, int LDS_STACK, class Load, class Store>
+template <bool FRONT_ONLY, bool COUNT, bool SPILL, class Load, class Store>
 __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint32_t* __restrict__ nextLine, float tMin,
                                             Counters& c, Load load, Store store) {
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t const lane = threadIdx.x & 63u;
     unsigned long long const below = (1ull << lane) - 1ull;
-    // The stack of deferred far children lives in LDS, one column per lane (entry i of lane l at
-    // [i][l]: conflict-free), when the tree is shallow enough for LDS_STACK entries; otherwise in
-    // scratch memory.
-    __shared__ uint32_t ldsStack[(LDS_STACK > 0 ? LDS_STACK : 1) * RT_BLOCK];
-    uint32_t scratchStack[LDS_STACK > 0 ? 1 : RT_STACK_MAX];
-    uint32_t* const stack = LDS_STACK > 0 ? ldsStack + threadIdx.x : scratchStack;
-    constexpr int STRIDE = LDS_STACK > 0 ? RT_BLOCK : 1;
+    // The stack of deferred far children: the first RT_LDS_STACK_DEPTH entries live in LDS, one column
+    // per lane (entry i of lane l at [i][l]: conflict-free); deeper entries, possible only in trees
+    // deeper than that (SPILL), go to scratch memory.
+    __shared__ uint32_t ldsStack[RT_LDS_STACK_DEPTH * RT_BLOCK];
+    uint32_t spillStack[SPILL ? RT_STACK_MAX - RT_LDS_STACK_DEPTH : 1];
+    uint32_t* const stack = ldsStack + threadIdx.x;
     // wave-uniform fetch state.  The first three quarters of the stream are dealt out statically, chunk
     // c to wave c mod waves (concurrent waves then work on neighbouring chunks, which keeps the caches
     // warm, and no atomic is needed); the rest is handed out through the cursor so that no wave is left
@@ -193,6 +240,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     uint32_t line = 0, cur = NONE;
     int sp = 0;
     V3 o = mk(0.0f, 0.0f, 0.0f), d = o, r = o;
+    float mu = INFINITY;
     bool fastDiv = false;
     HitRec best;
     best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
@@ -222,6 +270,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 load(line, o, d);
                 r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 fastDiv = S.fastDivision && coordInFastRange(o.x) && coordInFastRange(o.y) && coordInFastRange(o.z);
+                mu = filterMargin(o, d, r, S.boxAbsMax);
                 sp = 0; cur = 0;
                 best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
                 active = true;
@@ -242,7 +291,16 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             if (COUNT) c.boxTests++;
             int const index = __float_as_int(q1.z);
             uint32_t const aux = __float_as_uint(q1.w);
-            bool const meets = fastDiv ? lineBox<false>(o, d, r, lo, hi) : lineBox<true>(o, d, r, lo, hi);
+            int const sure = boxFilter(o, r, mu, lo, hi);
+            bool meets = sure > 0;
+            if (COUNT || sure == 0) {
+                bool const exact = fastDiv ? lineBox<false>(o, d, r, lo, hi) : lineBox<true>(o, d, r, lo, hi);
+                if (COUNT) {
+                    if (sure == 0) c.boxFallbacks++;
+                    else if (exact != meets) c.boxFilterErrors++;
+                }
+                meets = exact;
+            }
             if (meets && index > 0) {
                 if (COUNT) c.inodeVisits++;
                 float const la = aux == 0 ? lo.x : (aux == 1 ? lo.y : lo.z);
@@ -251,11 +309,18 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 float const plane = (la + ha) / 2.0f;
                 bool const positiveNear = (oa - plane) >= 0.0f;            // src/bsp.hpp:133
                 uint32_t const base = static_cast<uint32_t>(index);
-                stack[(sp++) * STRIDE] = positiveNear ? base : base + 1;    // far child
+                uint32_t const farChild = positiveNear ? base : base + 1;
+                if (!SPILL || sp < RT_LDS_STACK_DEPTH) stack[sp * RT_BLOCK] = farChild;
+                else spillStack[sp - RT_LDS_STACK_DEPTH] = farChild;
+                ++sp;
                 cur = positiveNear ? base + 1 : base;                       // near child
                 continue;
             }
-            cur = sp > 0 ? stack[(--sp) * STRIDE] : NONE;                   // what follows this node
+            if (sp > 0) {                                                   // what follows this node
+                --sp;
+                cur = (!SPILL || sp < RT_LDS_STACK_DEPTH) ? stack[sp * RT_BLOCK] : spillStack[sp - RT_LDS_STACK_DEPTH];
+            }
+            else cur = NONE;
             if (meets && index < 0) {
                 leafFirst = static_cast<uint32_t>(-(index + 1));
                 leafCount = aux;
@@ -359,8 +424,10 @@ __device__ __forceinline__ unsigned long long waveSum(unsigned long long v) {
 }
 __device__ __forceinline__ void flushCounters(const Counters& c, Counters* g) {
     unsigned long long const b = waveSum(c.boxTests), t = waveSum(c.trisTested), l = waveSum(c.leafVisits),
-                             i = waveSum(c.inodeVisits);
+                             i = waveSum(c.inodeVisits), f = waveSum(c.boxFallbacks), e = waveSum(c.boxFilterErrors);
     if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g->boxFallbacks, f);
+        atomicAdd(&g->boxFilterErrors, e);
         atomicAdd(&g->boxTests, b);
         atomicAdd(&g->trisTested, t);
         atomicAdd(&g->leafVisits, l);
@@ -369,13 +436,13 @@ __device__ __forceinline__ void flushCounters(const Counters& c, Counters* g) {
 }
 
 // rt_intersect: one lane per line.
-template <bool FRONT_ONLY, int LDS_STACK>
+template <bool FRONT_ONLY, bool SPILL>
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DevScene S, const float* __restrict__ origins,
                                                         const float* __restrict__ directions, uint32_t n,
                                                         float tMin, rt_hit* __restrict__ out,
                                                         uint32_t* __restrict__ nextLine) {
     Counters c = {};
-    traceStream<FRONT_ONLY, false, LDS_STACK>(
+    traceStream<FRONT_ONLY, false, SPILL>(
         S, n, nextLine, tMin, c,
         [&](uint32_t i, V3& o, V3& d) {
             o = mk(origins[3 * static_cast<size_t>(i)], origins[3 * static_cast<size_t>(i) + 1], origins[3 * static_cast<size_t>(i) + 2]);
@@ -434,13 +501,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P,
 // One closest-hit query per live path.  `bounce` selects the input queue; bounce 0 is the identity.
 // counts[RT_FETCH_BASE + bounce] is this launch's line-fetch cursor (zeroed with the counts).
 #define RT_FETCH_BASE 512u
-template <bool COUNT, int LDS_STACK>
+template <bool COUNT, bool SPILL>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, PathState P, uint32_t bounce, float tMin,
                                                     Counters* __restrict__ gc) {
     uint32_t const n = P.counts[bounce];
     uint32_t const* __restrict__ q = P.queue[bounce & 1];
     Counters c = {};
-    traceStream<true, COUNT, LDS_STACK>(
+    traceStream<true, COUNT, SPILL>(
         S, n, P.counts + RT_FETCH_BASE + bounce, tMin, c,
         [&](uint32_t i, V3& o, V3& d) {
             uint32_t const slot = bounce == 0 ? i : q[i];
@@ -668,6 +735,7 @@ struct rt_scene {
     void* wsQ0 = nullptr; void* wsQ1 = nullptr; void* wsCounts = nullptr; void* wsAccum = nullptr;
     void* wsCounters = nullptr;
     void* wsOut = nullptr; uint64_t wsOutPixels = 0;
+    std::vector<std::pair<const void*, int>> occupancy;   // resident blocks per CU of each persistent kernel
 };
 
 namespace {
@@ -681,6 +749,23 @@ void freeWorkspace(rt_scene* s) {
     s->wsPixels = 0;
 }
 
+// Grid of a persistent kernel: every block must be resident at once (the static share of the line
+// stream assumes all waves run concurrently), so the cap is the kernel's own occupancy.
+template <class Kernel>
+int persistentGrid(rt_scene* s, Kernel kernel, uint64_t items) {
+    const void* const key = reinterpret_cast<const void*>(kernel);
+    int perCu = 0;
+    for (auto const& kv : s->occupancy) if (kv.first == key) perCu = kv.second;
+    if (perCu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, RT_BLOCK, 0) != hipSuccess || perCu <= 0) perCu = 4;
+        if (std::getenv("RT_AMD_DEBUG")) std::fprintf(stderr, "rt_amd: persistent kernel %p: %d resident blocks per CU\n", key, perCu);
+        perCu = std::min(perCu, 8);
+        s->occupancy.emplace_back(key, perCu);
+    }
+    uint64_t const blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
+    return static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(blocks, static_cast<uint64_t>(s->cuCount) * perCu)));
+}
+
 int gridFor(const rt_scene* s, uint64_t items) {
     uint64_t const blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
     uint64_t const cap = static_cast<uint64_t>(s->cuCount) * 8;     // 8 blocks of 256 per CU = 32 waves/CU
@@ -692,7 +777,7 @@ int gridFor(const rt_scene* s, uint64_t items) {
 extern "C" {
 
 const char* rt_last_error(void) { return g_lastError.c_str(); }
-uint32_t rt_abi_version(void) { return 1; }
+uint32_t rt_abi_version(void) { return 2; }
 
 int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     if (!D || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
@@ -847,6 +932,9 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     s->dev.triNormals = static_cast<const float4*>(s->dTriNormals);
     s->dev.materials = static_cast<const float4*>(s->dMaterials);
     s->dev.fastDivision = fastDivision ? 1 : 0;
+    s->dev.boxAbsMax = 0.0f;
+    for (int k = 0; k < 3; ++k)
+        s->dev.boxAbsMax = std::max(s->dev.boxAbsMax, std::max(std::fabs(nodes[0].lo[k]), std::fabs(nodes[0].hi[k])));
     s->nodeCount = static_cast<uint32_t>(nodes.size());
     s->leafTriCount = refCount;
     s->depth = maxDepth;
@@ -886,13 +974,13 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
         uint32_t const m = static_cast<uint32_t>(std::min<uint64_t>(slice, n - done));
         uint32_t* cursor = static_cast<uint32_t*>(s->wsCounters) + 64;     // behind the Counters block
         HIP_TRY(hipMemsetAsync(cursor, 0, 4, st));
-        int const grid = gridFor(s, m);
-#define RT_LAUNCH_INTERSECT(FRONT, STACK)                                                                     \
-    hipLaunchKernelGGL((k_intersect<FRONT, STACK>), dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, d_origins + 3 * done, \
-                       d_directions + 3 * done, m, t_min, d_out + done, cursor)
-        bool const lds = s->depth <= RT_LDS_STACK_DEPTH;
-        if (front_only) { if (lds) RT_LAUNCH_INTERSECT(true, RT_LDS_STACK_DEPTH); else RT_LAUNCH_INTERSECT(true, 0); }
-        else { if (lds) RT_LAUNCH_INTERSECT(false, RT_LDS_STACK_DEPTH); else RT_LAUNCH_INTERSECT(false, 0); }
+#define RT_LAUNCH_INTERSECT(FRONT, SPILL)                                                                     \
+    hipLaunchKernelGGL((k_intersect<FRONT, SPILL>), dim3(persistentGrid(s, k_intersect<FRONT, SPILL>, m)),        \
+                       dim3(RT_BLOCK), 0, st, s->dev, d_origins + 3 * done, d_directions + 3 * done, m, t_min,    \
+                       d_out + done, cursor)
+        bool const spill = s->depth > RT_LDS_STACK_DEPTH;
+        if (front_only) { if (spill) RT_LAUNCH_INTERSECT(true, true); else RT_LAUNCH_INTERSECT(true, false); }
+        else { if (spill) RT_LAUNCH_INTERSECT(false, true); else RT_LAUNCH_INTERSECT(false, false); }
 #undef RT_LAUNCH_INTERSECT
     }
     HIP_TRY(hipGetLastError());
@@ -999,11 +1087,12 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
         mark(-1);
         for (uint32_t b = 0; b < bounceCount; ++b) {
             mark(1);
-#define RT_LAUNCH_TRACE(COUNT, STACK) \
-    hipLaunchKernelGGL((k_trace<COUNT, STACK>), dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc)
-            bool const lds = s->depth <= RT_LDS_STACK_DEPTH;
-            if (countWork) { if (lds) RT_LAUNCH_TRACE(true, RT_LDS_STACK_DEPTH); else RT_LAUNCH_TRACE(true, 0); }
-            else { if (lds) RT_LAUNCH_TRACE(false, RT_LDS_STACK_DEPTH); else RT_LAUNCH_TRACE(false, 0); }
+#define RT_LAUNCH_TRACE(COUNT, SPILL)                                                                         \
+    hipLaunchKernelGGL((k_trace<COUNT, SPILL>), dim3(persistentGrid(s, k_trace<COUNT, SPILL>, paths)),            \
+                       dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc)
+            bool const spill = s->depth > RT_LDS_STACK_DEPTH;
+            if (countWork) { if (spill) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
+            else { if (spill) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
 #undef RT_LAUNCH_TRACE
             mark(-1);
             mark(2);
@@ -1028,6 +1117,7 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
         stats->paths = hc.paths; stats->segments = hc.segments; stats->shaded_hits = hc.shadedHits;
         stats->box_tests = hc.boxTests; stats->tris_tested = hc.trisTested; stats->leaf_visits = hc.leafVisits;
         stats->inode_visits = hc.inodeVisits;
+        stats->box_exact_fallbacks = hc.boxFallbacks; stats->box_filter_errors = hc.boxFilterErrors;
         stats->trace_launches = traceLaunches; stats->batches = batches;
         if (profile) {
             double acc[4] = {0, 0, 0, 0};

@@ -205,6 +205,7 @@ def _assert_same_image_and_work(img, st, oimg, ost):
     assert st["shaded_hits"] == ost["shadedHits"]
     assert st["box_tests"] == ost["boxTests"] and st["tris_tested"] == ost["trisTested"]
     assert st["leaf_visits"] == ost["leafVisits"] and st["inode_visits"] == ost["inodeVisits"]
+    assert st["box_filter_errors"] == 0
 
 
 def test_render_builtin_bit_exact(oracle_lib):
@@ -398,3 +399,25 @@ def test_dragon_scale_scene_full_size(oracle_lib):
         assert np.isfinite(full).all() and full.max() > 0
     finally:
         ds.close(); osc.close()
+
+
+@pytest.mark.parametrize("name", ["builtin", "cornell", "displaced"])
+def test_box_filter_never_contradicts_exact_test(name):
+    """The production kernels decide most ray/box pairs with a conservative slab filter and fall back to the
+    reference's six-face test (src/geometry.hpp:135-214) otherwise.  The counting kernels run both on every
+    box: across a full 1080p frame no sure decision may differ, the fallback must stay rare, and the frame
+    rendered by the production kernels must equal the one rendered with the exact test alone."""
+    sc = {"builtin": lambda: scenes.builtin_scene(3), "cornell": scenes.cornell_scene,
+          "displaced": lambda: scenes.dragon_scale_scene(100_000)}[name]().preprocess()
+    ds = DeviceScene(RayTraceData(sc))
+    try:
+        w, h = 1920, 1080
+        p2r = sc.pixel_to_ray_transform(w, h)
+        counted, st = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=2, seed=5, flags=_lib.RT_FLAG_COUNT_WORK))
+        plain, _ = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=2, seed=5))
+        assert st["box_tests"] > 10_000_000
+        assert st["box_filter_errors"] == 0
+        assert st["box_exact_fallbacks"] < 0.10 * st["box_tests"], st
+        assert same_bits(counted, plain)
+    finally:
+        ds.close()
