@@ -238,6 +238,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     // per-lane line state
     bool active = false;
     uint32_t line = 0, cur = NONE;
+    uint32_t pend1 = NONE, pend2 = NONE;     // leaves (node records) found and not yet scanned
     int sp = 0;
     V3 o = mk(0.0f, 0.0f, 0.0f), d = o, r = o;
     float mu = INFINITY;
@@ -272,6 +273,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 fastDiv = S.fastDivision && coordInFastRange(o.x) && coordInFastRange(o.y) && coordInFastRange(o.z);
                 mu = filterMargin(o, d, r, S.boxAbsMax);
                 sp = 0; cur = 0;
+                pend1 = NONE; pend2 = NONE;
                 best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
                 active = true;
             }
@@ -282,19 +284,23 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
         if (!active) continue;
 
         // ---- phase 1: interior nodes until a leaf is reached or nothing is left ------------------
-        uint32_t leafFirst = 0, leafCount = 0;
-        V3 lo = mk(0.0f, 0.0f, 0.0f), hi = lo;
-        while (cur != NONE) {
+        // A lane that has found its leaf would idle until the slowest lane of the wave has found one
+        // too; instead it keeps walking and notes the next leaf its line meets (at most one ahead).
+        // If the first leaf yields a hit that work is discarded, otherwise it is already done; the
+        // sequence of leaves scanned is unchanged.  Kernels that count work do not look ahead, so
+        // that they count exactly the visits of the reference.
+        while (cur != NONE && pend2 == NONE) {
+            if (!COUNT) { if (__ballot(pend1 == NONE) == 0ull) break; }
             float4 const q0 = S.nodes[2 * cur];
             float4 const q1 = S.nodes[2 * cur + 1];
-            lo = mk(q0.x, q0.y, q0.z); hi = mk(q0.w, q1.x, q1.y);
+            V3 const nlo = mk(q0.x, q0.y, q0.z), nhi = mk(q0.w, q1.x, q1.y);
             if (COUNT) c.boxTests++;
             int const index = __float_as_int(q1.z);
             uint32_t const aux = __float_as_uint(q1.w);
-            int const sure = boxFilter(o, r, mu, lo, hi);
+            int const sure = boxFilter(o, r, mu, nlo, nhi);
             bool meets = sure > 0;
             if (COUNT || sure == 0) {
-                bool const exact = fastDiv ? lineBox<false>(o, d, r, lo, hi) : lineBox<true>(o, d, r, lo, hi);
+                bool const exact = fastDiv ? lineBox<false>(o, d, r, nlo, nhi) : lineBox<true>(o, d, r, nlo, nhi);
                 if (COUNT) {
                     if (sure == 0) c.boxFallbacks++;
                     else if (exact != meets) c.boxFilterErrors++;
@@ -303,8 +309,8 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             }
             if (meets && index > 0) {
                 if (COUNT) c.inodeVisits++;
-                float const la = aux == 0 ? lo.x : (aux == 1 ? lo.y : lo.z);
-                float const ha = aux == 0 ? hi.x : (aux == 1 ? hi.y : hi.z);
+                float const la = aux == 0 ? nlo.x : (aux == 1 ? nlo.y : nlo.z);
+                float const ha = aux == 0 ? nhi.x : (aux == 1 ? nhi.y : nhi.z);
                 float const oa = aux == 0 ? o.x : (aux == 1 ? o.y : o.z);
                 float const plane = (la + ha) / 2.0f;
                 bool const positiveNear = (oa - plane) >= 0.0f;            // src/bsp.hpp:133
@@ -316,60 +322,97 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 cur = positiveNear ? base + 1 : base;                       // near child
                 continue;
             }
+            uint32_t const here = cur;
             if (sp > 0) {                                                   // what follows this node
                 --sp;
                 cur = (!SPILL || sp < RT_LDS_STACK_DEPTH) ? stack[sp * RT_BLOCK] : spillStack[sp - RT_LDS_STACK_DEPTH];
             }
             else cur = NONE;
             if (meets && index < 0) {
-                leafFirst = static_cast<uint32_t>(-(index + 1));
-                leafCount = aux;
-                break;
+                if (pend1 == NONE) pend1 = here; else pend2 = here;
+                if (COUNT) break;
             }
         }
 
+        uint32_t leafFirst = 0, leafCount = 0;
+        V3 lo = mk(0.0f, 0.0f, 0.0f), hi = lo;
+        if (pend1 != NONE) {
+            float4 const q0 = S.nodes[2 * pend1];
+            float4 const q1 = S.nodes[2 * pend1 + 1];
+            lo = mk(q0.x, q0.y, q0.z); hi = mk(q0.w, q1.x, q1.y);
+            leafFirst = static_cast<uint32_t>(-(__float_as_int(q1.z) + 1));
+            leafCount = __float_as_uint(q1.w);
+            pend1 = pend2; pend2 = NONE;
+        }
+
         // ---- phase 2: the leaf's triangles, src/bsp.hpp:58-104 -------------------------------------
+        // lineTrisIntersection, src/geometry.hpp:117-132 (one lane of the 8-wide form), in two passes.
+        // Pass 1 runs every triangle up to the point where the signs of the barycentric numerators
+        // are known and notes the few that can still be hits; pass 2 finishes those in ascending order
+        // (division, t, in-box test, strict < against the best so far), which is the order and the
+        // arithmetic of the reference's scan.  Splitting keeps the long tail of the test out of the loop
+        // that all lanes share: it would otherwise be issued for a handful of lanes on almost every
+        // triangle.
         bool has = false;
         if (leafCount != 0) {
             if (COUNT) { c.leafVisits++; c.trisTested += leafCount; }
-            for (uint32_t j = 0; j < leafCount; ++j) {
-                float4 const* tp = S.leafTris + 4 * static_cast<size_t>(leafFirst + j);
-                // lineTrisIntersection, src/geometry.hpp:117-132 (one lane of the 8-wide form).  The
-                // facing test needs only the first 16 bytes of the record; lanes that fail it do not
-                // fetch the rest (scattered 16-byte loads are what this kernel is bound by).
-                float4 a = tp[0];
-                asm volatile("" : "+v"(a.w));       // keep the first fetch one 16-byte load
-                V3 const nrm = mk(a.x, a.y, a.z);
-                float const negDet = dotF(nrm, d);
-                bool const detOk = FRONT_ONLY ? (negDet <= -1e-6f) : (fabsf(negDet) >= 1e-6f);
-                if (!detOk) continue;
-                float4 const b = tp[1], e = tp[2];
-                V3 const v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x), e12 = mk(e.y, e.z, e.w);
-                V3 const AO = o - v1;
-                V3 const DAO = crossF(AO, d);
-                float const du = dotF(e13, DAO);
-                float const dv = dotF(e12, DAO);
-                if (FRONT_ONLY) {
-                    // u = du*invDet and v = (0-dv)*invDet with 0 < invDet = 1/|negDet|.  A negative
-                    // numerator gives a negative product unless the product underflows to -0; with
-                    // |numerator| > 2^-60 and |negDet| < 2^60 it cannot, so the sign decides without
-                    // the division.
-                    if ((du < -0x1p-60f || dv > 0x1p-60f) && negDet > -0x1p60f) continue;
+            for (uint32_t window = 0; window < leafCount; window += 32u) {
+                uint32_t const windowEnd = min(leafCount, window + 32u);
+                uint32_t candidates = 0;
+                for (uint32_t j = window; j < windowEnd; ++j) {
+                    float4 const* tp = S.leafTris + 4 * static_cast<size_t>(leafFirst + j);
+                    // The facing test needs only the first 16 bytes of the record; lanes that fail it
+                    // do not fetch the rest.
+                    float4 a = tp[0];
+                    asm volatile("" : "+v"(a.w));       // keep the first fetch one 16-byte load
+                    V3 const nrm = mk(a.x, a.y, a.z);
+                    float const negDet = dotF(nrm, d);
+                    bool const detOk = FRONT_ONLY ? (negDet <= -1e-6f) : (fabsf(negDet) >= 1e-6f);
+                    if (!detOk) continue;
+                    if (FRONT_ONLY) {
+                        float4 const b = tp[1], e = tp[2];
+                        V3 const v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x), e12 = mk(e.y, e.z, e.w);
+                        V3 const AO = o - v1;
+                        V3 const DAO = crossF(AO, d);
+                        float const du = dotF(e13, DAO);
+                        float const dv = dotF(e12, DAO);
+                        // u = du*invDet and v = (0-dv)*invDet with 0 < invDet = RN(1/|negDet|).  A negative
+                        // numerator gives a negative product unless the product underflows to -0; with
+                        // |numerator| > 2^-60 and |negDet| < 2^60 it cannot, so the sign decides without
+                        // the division.  Likewise u + v, a sum of two non-negative roundings of
+                        // numerator/|negDet| with a relative error below 2^-22, exceeds 1 whenever
+                        // du - dv exceeds |negDet| by a factor 1 + 2^-20.
+                        bool const tame = negDet > -0x1p60f;
+                        if ((du < -0x1p-60f || dv > 0x1p-60f) && tame) continue;
+                        if (du >= 0.0f && dv <= 0.0f && tame && negDet < -0x1p-60f && (du - dv) > -negDet * (1.0f + 0x1p-20f)) continue;
+                    }
+                    candidates |= 1u << (j - window);
                 }
-                float const invDet = -1.0f / negDet;
-                float const u = du * invDet;
-                float const v = (0.0f - dv) * invDet;
-                if (!(u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f)) continue;
-                float const t = dotF(AO, nrm) * invDet;
-                if (!(t < best.t && t >= tMin)) continue;                   // src/bsp.hpp:79
-                V3 const p = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
-                bool const inBox = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z
-                                && p.z <= hi.z;
-                if (inBox) { best.t = t; best.u = u; best.v = v; best.ref = leafFirst + j; has = true; }
+                while (candidates != 0u) {
+                    uint32_t const j = window + static_cast<uint32_t>(__ffs(static_cast<int>(candidates)) - 1);
+                    candidates &= candidates - 1u;
+                    float4 const* tp = S.leafTris + 4 * static_cast<size_t>(leafFirst + j);
+                    float4 const a = tp[0], b = tp[1], e = tp[2];
+                    V3 const nrm = mk(a.x, a.y, a.z);
+                    float const negDet = dotF(nrm, d);
+                    V3 const v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x), e12 = mk(e.y, e.z, e.w);
+                    V3 const AO = o - v1;
+                    V3 const DAO = crossF(AO, d);
+                    float const invDet = -1.0f / negDet;
+                    float const u = dotF(e13, DAO) * invDet;
+                    float const v = (0.0f - dotF(e12, DAO)) * invDet;
+                    if (!(u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f)) continue;
+                    float const t = dotF(AO, nrm) * invDet;
+                    if (!(t < best.t && t >= tMin)) continue;                   // src/bsp.hpp:79
+                    V3 const p = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+                    bool const inBox = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z
+                                    && p.z <= hi.z;
+                    if (inBox) { best.t = t; best.u = u; best.v = v; best.ref = leafFirst + j; has = true; }
+                }
             }
         }
         // First leaf with an accepted hit ends the search (src/bsp.hpp:136-138); so does running out of nodes.
-        if (has || cur == NONE) {
+        if (has || (cur == NONE && pend1 == NONE)) {
             store(line, best, o, d);
             active = false;
         }
