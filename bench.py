@@ -54,7 +54,9 @@ def cpu_baseline(scene, width, height, bounce_limit, target_seconds=12.0):
     from oracle import binding
     from helpers import base_from_scene
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    osc = binding.oracle().scene_create(base_from_scene(scene), width, height)
+    # The oracle traverses the tree the product's builder made (identical to the reference's own build,
+    # which is O(nodes x triangles) and would take hours on the large workloads).
+    osc = binding.oracle().scene_create_with_tree(base_from_scene(scene), width, height, scene.bsp_tree)
     try:
         t0 = time.perf_counter()
         _, st = osc.render_device_mode(osc.render_params(1, bounce_limit=bounce_limit), threads=threads)

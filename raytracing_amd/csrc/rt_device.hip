@@ -238,7 +238,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     // per-lane line state
     bool active = false;
     uint32_t line = 0, cur = NONE;
-    uint32_t pend1 = NONE, pend2 = NONE;     // leaves (node records) found and not yet scanned
+    uint32_t pend1 = NONE, pend2 = NONE, pend3 = NONE;     // leaves (node records) found and not yet scanned, oldest first
     int sp = 0;
     V3 o = mk(0.0f, 0.0f, 0.0f), d = o, r = o;
     float mu = INFINITY;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 fastDiv = S.fastDivision && coordInFastRange(o.x) && coordInFastRange(o.y) && coordInFastRange(o.z);
                 mu = filterMargin(o, d, r, S.boxAbsMax);
                 sp = 0; cur = 0;
-                pend1 = NONE; pend2 = NONE;
+                pend1 = NONE; pend2 = NONE; pend3 = NONE;
                 best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
                 active = true;
             }
@@ -285,11 +285,11 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
 
         // ---- phase 1: interior nodes until a leaf is reached or nothing is left ------------------
         // A lane that has found its leaf would idle until the slowest lane of the wave has found one
-        // too; instead it keeps walking and notes the next leaf its line meets (at most one ahead).
+        // too; instead it keeps walking and notes the next leaves its line meets (at most two ahead).
         // If the first leaf yields a hit that work is discarded, otherwise it is already done; the
         // sequence of leaves scanned is unchanged.  Kernels that count work do not look ahead, so
         // that they count exactly the visits of the reference.
-        while (cur != NONE && pend2 == NONE) {
+        while (cur != NONE && pend3 == NONE) {
             if (!COUNT) { if (__ballot(pend1 == NONE) == 0ull) break; }
             float4 const q0 = S.nodes[2 * cur];
             float4 const q1 = S.nodes[2 * cur + 1];
@@ -329,7 +329,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             }
             else cur = NONE;
             if (meets && index < 0) {
-                if (pend1 == NONE) pend1 = here; else pend2 = here;
+                if (pend1 == NONE) pend1 = here; else if (pend2 == NONE) pend2 = here; else pend3 = here;
                 if (COUNT) break;
             }
         }
@@ -342,7 +342,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             lo = mk(q0.x, q0.y, q0.z); hi = mk(q0.w, q1.x, q1.y);
             leafFirst = static_cast<uint32_t>(-(__float_as_int(q1.z) + 1));
             leafCount = __float_as_uint(q1.w);
-            pend1 = pend2; pend2 = NONE;
+            pend1 = pend2; pend2 = pend3; pend3 = NONE;
         }
 
         // ---- phase 2: the leaf's triangles, src/bsp.hpp:58-104 -------------------------------------
