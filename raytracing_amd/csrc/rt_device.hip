@@ -163,6 +163,7 @@ __device__ __forceinline__ bool coordInFastRange(float x) {
 //   surely meets:  the exit face (smallest far crossing time tX) has tX > theta, the line is inside the
 //     two other slabs at tX by more than theta (tX - tE > theta and second-smallest far time - tX >
 //     theta), and no direction component is below 2^-16 (else mu = inf): that face's test is true.
+//   (originInsideRule adds a third sure case.)
 //   surely misses: tX < -theta (on some axis the box lies behind the origin by a margin: every face
 //     either has t < 0 or lies beyond that slab), or tE - tX > 2 mu + 2^-20 (|tE| + |tX|) (every
 //     crossing time is clear of the slab of the latest-entered or of the earliest-left axis).
@@ -175,7 +176,8 @@ __device__ __forceinline__ float filterMargin(V3 o, V3 d, V3 r, float boxAbsMax)
     return dMin >= 0x1p-16f ? m * rMax : INFINITY;
 }
 
-// +1 surely meets, -1 surely misses, 0 undecided.
+// Bit 0: surely meets; bit 1: surely misses; bit 2: the exit face is clear of the other two slabs' far
+// planes (used by the origin-inside rule below).
 __device__ __forceinline__ int boxFilter(V3 o, V3 r, float mu, V3 lo, V3 hi) {
     float const ax = (lo.x - o.x) * r.x, bx = (hi.x - o.x) * r.x;
     float const ay = (lo.y - o.y) * r.y, by = (hi.y - o.y) * r.y;
@@ -185,10 +187,22 @@ __device__ __forceinline__ int boxFilter(V3 o, V3 r, float mu, V3 lo, V3 hi) {
     float const tX = fminf(fminf(xx, xy), xz);
     float const second = __builtin_amdgcn_fmed3f(xx, xy, xz);
     float const theta = 0x1p-20f * fabsf(tX) + mu;
-    bool const sureHit = (tX - tE > theta) & (second - tX > theta) & (tX > theta);
+    bool const exitClear = second - tX > theta;
+    bool const sureHit = (tX - tE > theta) & exitClear & (tX > theta);
     float const theta2 = 0x1p-20f * (fabsf(tE) + fabsf(tX)) + (mu + mu);
     bool const sureMiss = (tX < -theta) | (tE - tX > theta2);
-    return sureHit ? 1 : (sureMiss ? -1 : 0);
+    return (sureHit ? 1 : 0) | (sureMiss ? 2 : 0) | (exitClear ? 4 : 0);
+}
+
+// Origin-inside rule for pairs the filter left open (typically an origin lying exactly on a plane of
+// the box: a camera placed on a split plane of the tree, a path vertex on a wall that coincides with a
+// box face).  If the origin is inside the closed box (exact comparisons) and the exit face is clear of
+// the other slabs' far planes, the reference's test of the exit face succeeds: its t is a quotient of
+// two numbers of equal sign (or zero), hence >= 0; on the other axes the point o_b + t d_b has moved
+// from o_b towards the far plane, so rounding cannot take it back below the near plane
+// (RN(o_b + x) >= o_b for x >= 0), and it stays below the far plane by the margin exitClear provides.
+__device__ __forceinline__ bool originInsideRule(int filterBits, V3 o, V3 lo, V3 hi) {
+    return (filterBits & 4) != 0 && o.x >= lo.x && o.x <= hi.x && o.y >= lo.y && o.y <= hi.y && o.z >= lo.z && o.z <= hi.z;
 }
 
 struct HitRec {
@@ -297,15 +311,19 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             if (COUNT) c.boxTests++;
             int const index = __float_as_int(q1.z);
             uint32_t const aux = __float_as_uint(q1.w);
-            int const sure = boxFilter(o, r, mu, nlo, nhi);
-            bool meets = sure > 0;
-            if (COUNT || sure == 0) {
-                bool const exact = fastDiv ? lineBox<false>(o, d, r, nlo, nhi) : lineBox<true>(o, d, r, nlo, nhi);
-                if (COUNT) {
-                    if (sure == 0) c.boxFallbacks++;
-                    else if (exact != meets) c.boxFilterErrors++;
+            int const filterBits = boxFilter(o, r, mu, nlo, nhi);
+            bool meets = (filterBits & 1) != 0;
+            bool decided = (filterBits & 3) != 0;
+            if (COUNT || !decided) {
+                if (!decided && originInsideRule(filterBits, o, nlo, nhi)) { meets = true; decided = true; }
+                if (COUNT || !decided) {
+                    bool const exact = fastDiv ? lineBox<false>(o, d, r, nlo, nhi) : lineBox<true>(o, d, r, nlo, nhi);
+                    if (COUNT) {
+                        if (!decided) c.boxFallbacks++;
+                        else if (exact != meets) c.boxFilterErrors++;
+                    }
+                    meets = exact;
                 }
-                meets = exact;
             }
             if (meets && index > 0) {
                 if (COUNT) c.inodeVisits++;

@@ -417,7 +417,7 @@ def test_box_filter_never_contradicts_exact_test(name):
         plain, _ = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=2, seed=5))
         assert st["box_tests"] > 10_000_000
         assert st["box_filter_errors"] == 0
-        assert st["box_exact_fallbacks"] < 0.10 * st["box_tests"], st
+        assert st["box_exact_fallbacks"] < 0.05 * st["box_tests"], st
         assert same_bits(counted, plain)
     finally:
         ds.close()

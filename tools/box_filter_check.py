@@ -29,9 +29,13 @@ def filter_decisions(o, d, lo, hi, mbox):
         med = np.sort(tx, axis=1)[:, 1]
         theta = (f32(2.0 ** -20) * np.abs(tX) + mu).astype(f32)
         gap = (tX - tE).astype(f32)
-        sure_hit = (gap > theta) & ((med - tX).astype(f32) > theta) & (tX > theta)
+        exit_clear = (med - tX).astype(f32) > theta
+        sure_hit = (gap > theta) & exit_clear & (tX > theta)
         theta2 = (f32(2.0 ** -20) * (np.abs(tE) + np.abs(tX)).astype(f32) + (mu + mu).astype(f32)).astype(f32)
         sure_miss = (tX < -theta) | ((tE - tX).astype(f32) > theta2)
+        # origin-inside rule, applied only to pairs still open
+        inside = ((o >= lo) & (o <= hi)).all(axis=1)
+        sure_hit = sure_hit | (~sure_hit & ~sure_miss & exit_clear & inside)
     return sure_hit, sure_miss
 
 
@@ -55,6 +59,11 @@ def main():
         lo = (c - ext).astype(f32); hi = (c + ext).astype(f32)
         mbox = max(np.abs(lo).max(), np.abs(hi).max())
         o = (rng.uniform(-2, 2, (n, 3)) * scale).astype(f32)
+        # a quarter of the origins inside the box or exactly on its planes
+        w = rng.uniform(0, 1, (n, 3))
+        w = np.where(rng.random((n, 3)) < 0.4, np.round(w), w)
+        o = np.where((rng.random(n) < 0.25)[:, None], (lo + (hi - lo) * w).astype(f32), o).astype(f32)
+        o = np.where((rng.random(n) < 0.1)[:, None] & (rng.random((n, 3)) < 0.5), np.where(rng.random((n, 3)) < 0.5, lo, hi), o).astype(f32)
         kind = rng.integers(0, 5, n)
         # target point: random / on a face / on an edge / at a corner of the box
         u = rng.uniform(0, 1, (n, 3))
