@@ -136,6 +136,16 @@ int rt_render(rt_scene* scene, const rt_render_params* params, float* out_rgb, r
 int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_out_rgb, rt_stats* stats,
                      void* hip_stream);
 
+/* The steps between render() and the image file (src/main.cpp:233-240): reinhardToneMap, linearToSRGB,
+ * nanToRed, infToGreen (src/image.hpp:15-70), medianFilter<1> (:73-109) and floatTo8BitUInt (:48-50).
+ * hdr: width*height*3 floats as written by rt_render; rgb8: width*height*3 bytes, the payload of the
+ * reference's P6 file.  d_srgb (width*height*3 floats, must not alias d_hdr) receives the frame before the
+ * median; d_median (optional, same size) the frame after it.  Border pixels of the median use their
+ * in-image neighbours only (the reference's border values depend on stale array contents). */
+int rt_postprocess_device(const float* d_hdr, uint32_t width, uint32_t height, float* d_srgb, float* d_median,
+                          uint8_t* d_rgb8, void* hip_stream);
+int rt_postprocess(int device, const float* hdr, uint32_t width, uint32_t height, uint8_t* rgb8);
+
 /* Test hook: evaluates one scalar building block of the kernels on the GPU for n inputs so that its
  * bits can be pinned: op 0 a/b, 1 sqrt(a), 2 sin,cos(2*pi*a) (2 outputs), 3 Philox words (2 outputs),
  * 4 fma(a,b,a), 5 a*b+a unfused, 6 a/b through the reciprocal-based sequence the box test uses.  Not part of

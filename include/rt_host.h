@@ -50,6 +50,10 @@ void rt_scene_bounding_box(const float* inst_positions, uint64_t vertex_count, i
 float rt_srgb_to_linear(float srgb);
 float rt_linear_to_srgb(float linear);
 
+/* The image file of src/main.cpp:272-280: binary PPM, "P6\n<width> <height>\n255\n" followed by
+ * width*height*3 bytes.  Returns 0, or -1 if the file cannot be written. */
+int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
 /* lineIntersectsBox (src/geometry.hpp:135-214) and triIntersectsBox (src/geometry.hpp:217-428). */
 int rt_line_intersects_box(const float origin[3], const float direction[3], const float box[6]);
 int rt_tri_intersects_box(const float tri[9], const float box[6]);

@@ -98,6 +98,31 @@ class _Lib:
         self._f("tri_intersects_box")(_p(t), _p(b), _c.c_size_t(n), _p(out))
         return out
 
+    # -- post-processing (src/main.cpp:233-240) -----------------------------------------------
+    def tone_srgb_flags(self, hdr):
+        h = np.ascontiguousarray(hdr, np.float32)
+        out = np.empty_like(h)
+        self._f("tone_srgb_flags")(_p(h), _c.c_size_t(h.size // 3), _p(out))
+        return out
+
+    def median3(self, image):
+        a = np.ascontiguousarray(image, np.float32)
+        height, width = a.shape[0], a.shape[1]
+        out = np.empty_like(a)
+        self._f("median3")(_p(a), _c.c_uint32(width), _c.c_uint32(height), _p(out))
+        return out
+
+    def to_u8(self, image):
+        a = np.ascontiguousarray(image, np.float32)
+        out = np.empty(a.shape, np.uint8)
+        n = a.size if not self.is_ref else a.size // 3
+        self._f("to_u8")(_p(a), _c.c_size_t(n), _p(out))
+        return out
+
+    def postprocess(self, hdr):
+        """HDR (h, w, 3) float32 -> (h, w, 3) uint8, the whole of src/main.cpp:233-240."""
+        return self.to_u8(self.median3(self.tone_srgb_flags(hdr)))
+
     # -- scenes ----------------------------------------------------------------------------
     def scene_create(self, base, width, height):
         idx_t = np.uint16 if self.is_ref else np.uint32

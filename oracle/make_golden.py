@@ -131,5 +131,31 @@ def main():
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 
 
+def postprocess_golden():
+    """(g) src/main.cpp:233-240 applied by the compiled reference to the converged frame of (e), with a
+    few special pixels injected (NaN, +-inf, negative, zero, tiny)."""
+    R = B.reference()
+    assert R is not None, "build oracle/_ref/libref.so first (oracle/build_ref.sh)"
+    hdr = np.load(os.path.join(OUT, "builtin_converged_160x120.npz"))["image"].reshape(120, 160, 3).copy()
+    hdr[3, 4, 1] = np.nan
+    hdr[10, 10, 0] = np.inf
+    hdr[11, 12, 2] = -1.0
+    hdr[20, 20, 1] = -np.inf
+    hdr[5, 5] = 0.0
+    hdr[6, 6, 0] = -0.5
+    hdr[7, 7] = 1e-4
+    hdr[8, 8] = 0.0031308 / (1 - 0.0031308)
+    srgb = R.tone_srgb_flags(hdr)
+    median = R.median3(srgb)
+    rgb8 = R.to_u8(median)
+    np.savez_compressed(os.path.join(OUT, "postprocess_160x120.npz"), hdr=hdr, ref_srgb=srgb, ref_median=median,
+                        ref_rgb8=rgb8)
+    print("postprocess_160x120.npz", os.path.getsize(os.path.join(OUT, "postprocess_160x120.npz")))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "postprocess":
+        postprocess_golden()
+    else:
+        main()
+        postprocess_golden()

@@ -407,4 +407,33 @@ void ref_render(void* h, unsigned spp, std::uint64_t seed, float* image) {
     }
 }
 
+// Post-processing exactly as src/main.cpp:233-240 applies it.
+void ref_tone_srgb_flags(const float* hdr, std::size_t pixels, float* out) {
+    std::vector<glm::vec3> buf(pixels);
+    std::memcpy(buf.data(), hdr, pixels * 12);
+    std::transform(buf.cbegin(), buf.cend(), buf.begin(), reinhardToneMap);
+    std::transform(buf.cbegin(), buf.cend(), buf.begin(), static_cast<glm::vec3(*)(glm::vec3)>(linearToSRGB));
+    std::transform(buf.cbegin(), buf.cend(), buf.begin(), nanToRed);
+    std::transform(buf.cbegin(), buf.cend(), buf.begin(), infToGreen);
+    std::memcpy(out, buf.data(), pixels * 12);
+}
+
+void ref_median3(const float* image, unsigned width, unsigned height, float* out) {
+    std::size_t const pixels = static_cast<std::size_t>(width) * height;
+    std::vector<glm::vec3> in(pixels), res(pixels);
+    std::memcpy(in.data(), image, pixels * 12);
+    std::copy(in.cbegin(), in.cend(), res.begin());
+    medianFilter<1>(readOnlySpan(in), width, Span{res});
+    std::memcpy(out, res.data(), pixels * 12);
+}
+
+void ref_to_u8(const float* image, std::size_t pixels, std::uint8_t* out) {
+    for (std::size_t i = 0; i < pixels; ++i) {
+        glm::vec3 p;
+        std::memcpy(&p, image + 3 * i, 12);
+        glm::u8vec3 const q = floatTo8BitUInt(p);
+        out[3 * i] = q.x; out[3 * i + 1] = q.y; out[3 * i + 2] = q.z;
+    }
+}
+
 }  // extern "C"

@@ -877,3 +877,77 @@ void orc_render_device_mode(const orc_scene* s, const orc_render_params* p, floa
     }
     if (stats) *stats = total;
 }
+
+/* ---- post-processing (src/main.cpp:233-240, src/image.hpp:15-109) ------------------------------- */
+
+/* src/image.hpp:20-27; std::pow(float, float) is libm's powf. */
+static float linear_to_srgb(float linear) {
+    if (linear <= 0.0031308f) return linear * 12.92f;
+    return 1.055f * powf(linear, 1.0f / 2.4f) - 0.055f;
+}
+
+/* Per pixel, in the order of src/main.cpp:233-237: Reinhard (image.hpp:15-17), sRGB transfer
+ * (:20-31), NaN -> red (:53-60), Inf -> green (:63-70). */
+void orc_tone_srgb_flags(const float* hdr, size_t pixels, float* out) {
+    for (size_t i = 0; i < pixels; ++i) {
+        float c[3];
+        for (int k = 0; k < 3; ++k) {
+            float const h = hdr[3 * i + k];
+            c[k] = linear_to_srgb(h / (1.0f + h));
+        }
+        if (isnan(c[0]) || isnan(c[1]) || isnan(c[2])) { c[0] = 1.0f; c[1] = 0.0f; c[2] = 0.0f; }
+        if (isinf(c[0]) || isinf(c[1]) || isinf(c[2])) { c[0] = 0.0f; c[1] = 1.0f; c[2] = 0.0f; }
+        out[3 * i] = c[0]; out[3 * i + 1] = c[1]; out[3 * i + 2] = c[2];
+    }
+}
+
+static int cmp_float(const void* a, const void* b) {
+    float const x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* medianFilter<1>, src/image.hpp:73-109: per channel, the element of rank neighbours/2 among the
+ * in-image neighbours of the 3x3 window.  Interior pixels (9 neighbours) are what the reference
+ * computes.  On the image border the reference selects among all 9 array slots although only 4 or 6
+ * were written for this pixel (:83-85, :103-105: stale values of earlier pixels, uninitialised for the
+ * first ones, in an order that depends on the standard library's nth_element); that is not
+ * reproducible and not restated: border pixels here use the written values only. */
+void orc_median3(const float* image, uint32_t width, uint32_t height, float* out) {
+    for (int64_t i = 0; i < (int64_t)height; ++i)
+        for (int64_t j = 0; j < (int64_t)width; ++j) {
+            float ch[3][9];
+            unsigned n = 0;
+            for (int64_t di = -1; di <= 1; ++di)
+                for (int64_t dj = -1; dj <= 1; ++dj) {
+                    int64_t const y = i + di, x = j + dj;
+                    if (y >= 0 && x >= 0 && y < (int64_t)height && x < (int64_t)width) {
+                        const float* p = image + 3 * (y * (int64_t)width + x);
+                        ch[0][n] = p[0]; ch[1][n] = p[1]; ch[2][n] = p[2];
+                        ++n;
+                    }
+                }
+            for (int k = 0; k < 3; ++k) {
+                qsort(ch[k], n, sizeof(float), cmp_float);
+                out[3 * (i * (int64_t)width + j) + k] = ch[k][n / 2];
+            }
+        }
+}
+
+/* floatTo8BitUInt, src/image.hpp:48-50: clamp(255*x, 0, 255) then conversion to uint8 (truncation). */
+void orc_to_u8(const float* image, size_t values, uint8_t* out) {
+    for (size_t i = 0; i < values; ++i) {
+        float v = 255.0f * image[i];
+        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);     /* glm::clamp = min(max(x, lo), hi) */
+        out[i] = (uint8_t)v;
+    }
+}
+
+void orc_postprocess(const float* hdr, uint32_t width, uint32_t height, uint8_t* rgb8) {
+    size_t const pixels = (size_t)width * height;
+    float* a = (float*)malloc(pixels * 12 + 12);
+    float* b = (float*)malloc(pixels * 12 + 12);
+    orc_tone_srgb_flags(hdr, pixels, a);
+    orc_median3(a, width, height, b);
+    orc_to_u8(b, pixels * 3, rgb8);
+    free(a); free(b);
+}

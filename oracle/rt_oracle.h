@@ -125,6 +125,16 @@ void orc_sincos_2pi(float u, float* s, float* c);
 void orc_path_radiance_device_mode(const orc_scene*, const orc_render_params*, uint32_t pixelX, uint32_t pixelY,
                                    uint32_t sample, float rgb[3], orc_stats* stats);
 
+/* ---- post-processing, src/main.cpp:233-240 ---------------------------------------------------- */
+/* Reinhard + sRGB transfer + NaN->red + Inf->green per pixel (src/image.hpp:15-70). */
+void orc_tone_srgb_flags(const float* hdr, size_t pixels, float* out);
+/* medianFilter<1> (src/image.hpp:73-109); border pixels use their in-image neighbours only (the
+ * reference's border values depend on stale array contents and are not reproducible). */
+void orc_median3(const float* image, uint32_t width, uint32_t height, float* out);
+/* floatTo8BitUInt (src/image.hpp:48-50). */
+void orc_to_u8(const float* image, size_t values, uint8_t* out);
+void orc_postprocess(const float* hdr, uint32_t width, uint32_t height, uint8_t* rgb8);
+
 #ifdef __cplusplus
 }
 #endif

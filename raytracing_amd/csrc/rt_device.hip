@@ -835,6 +835,9 @@ int gridFor(const rt_scene* s, uint64_t items) {
 
 }  // namespace
 
+// Error reporting for the other translation units of the library.
+int rt_internal_fail(int code, const char* message) { return fail(code, message ? message : ""); }
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_lastError.c_str(); }

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -67,6 +68,18 @@ float rt_srgb_to_linear(float srgb) {
 float rt_linear_to_srgb(float linear) {
     // src/image.hpp:20-27
     return linear <= 0.0031308f ? linear * 12.92f : 1.055f * std::pow(linear, 1.0f / 2.4f) - 0.055f;
+}
+
+int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    // src/main.cpp:272-280
+    if (!path || (!rgb8 && width && height)) return -1;
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) return -1;
+    size_t const bytes = static_cast<size_t>(width) * height * 3;
+    bool ok = std::fprintf(f, "P6\n%u %u\n255\n", width, height) > 0;
+    ok = ok && (bytes == 0 || std::fwrite(rgb8, 1, bytes, f) == bytes);
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? 0 : -1;
 }
 
 void rt_quat_from_euler(const float e[3], float q[4]) {

@@ -158,3 +158,14 @@ def test_oracle_traverses_supplied_tree_like_its_own(oracle_lib):
         assert same_bits(own.render_device_mode(pa, threads=4)[0], given.render_device_mode(pb, threads=4)[0])
     finally:
         own.close(); given.close()
+
+
+def test_ppm_writer_matches_reference_file_layout(tmp_path):
+    """src/main.cpp:272-280: 'P6', width and height separated by a space, '255', then the raw bytes."""
+    from raytracing_amd import image
+    rgb = (np.arange(5 * 7 * 3) % 251).astype(np.uint8).reshape(5, 7, 3)
+    path = tmp_path / "out.ppm"
+    image.write_ppm(path, rgb)
+    assert path.read_bytes() == b"P6\n7 5\n255\n" + rgb.tobytes()
+    with pytest.raises(OSError):
+        image.write_ppm(tmp_path / "missing_dir" / "x.ppm", rgb)
