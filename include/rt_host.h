@@ -54,6 +54,19 @@ float rt_linear_to_srgb(float linear);
  * width*height*3 bytes.  Returns 0, or -1 if the file cannot be written. */
 int rt_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 
+/* One entry of the Meshes initializer list (src/scene.cpp:8-30: positions, normals, indexed triangles
+ * with one index per vertex) read from a Wavefront OBJ or a PLY file (ascii or binary_little_endian).
+ * The reference has no loader (its meshes are the literals of src/main.cpp:25-121).  Polygons become
+ * fans; OBJ position/normal index pairs become single vertices; missing normals are replaced by
+ * area-weighted vertex normals.  Returns 0 or -1 (message in rt_mesh_last_error). */
+typedef struct rt_mesh_file rt_mesh_file;
+int rt_mesh_load(const char* path, rt_mesh_file** out);
+void rt_mesh_counts(const rt_mesh_file* mesh, uint32_t* vertex_count, uint32_t* tri_count);
+/* positions, normals: 3 floats per vertex; tris: 3 indices per triangle.  Valid until rt_mesh_destroy. */
+void rt_mesh_view(const rt_mesh_file* mesh, const float** positions, const float** normals, const uint32_t** tris);
+void rt_mesh_destroy(rt_mesh_file* mesh);
+const char* rt_mesh_last_error(void);
+
 /* lineIntersectsBox (src/geometry.hpp:135-214) and triIntersectsBox (src/geometry.hpp:217-428). */
 int rt_line_intersects_box(const float origin[3], const float direction[3], const float box[6]);
 int rt_tri_intersects_box(const float tri[9], const float box[6]);

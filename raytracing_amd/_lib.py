@@ -68,7 +68,8 @@ DEVICE_SYMBOLS = ["rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_in
                   "rt_last_error", "rt_abi_version"]
 HOST_SYMBOLS = ["rt_preprocess_material", "rt_quat_from_euler", "rt_camera_basis", "rt_pixel_to_ray_transform",
                 "rt_instantiate_meshes", "rt_preprocess_tris", "rt_scene_bounding_box", "rt_line_intersects_box",
-                "rt_tri_intersects_box", "rt_srgb_to_linear", "rt_linear_to_srgb", "rt_bsp_build", "rt_bsp_destroy", "rt_bsp_counts", "rt_bsp_view", "rt_write_ppm"]
+                "rt_tri_intersects_box", "rt_srgb_to_linear", "rt_linear_to_srgb", "rt_bsp_build", "rt_bsp_destroy", "rt_bsp_counts", "rt_bsp_view", "rt_write_ppm",
+                "rt_mesh_load", "rt_mesh_counts", "rt_mesh_view", "rt_mesh_destroy", "rt_mesh_last_error"]
 
 _lib = None
 
@@ -89,6 +90,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.rt_last_error.restype = ctypes.c_char_p
         L.rt_abi_version.restype = c_u32
+        L.rt_mesh_last_error.restype = ctypes.c_char_p
         L.rt_srgb_to_linear.restype = c_f32
         L.rt_srgb_to_linear.argtypes = [c_f32]
         L.rt_linear_to_srgb.restype = c_f32

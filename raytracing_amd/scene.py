@@ -5,6 +5,7 @@ with snake_case attributes; the arithmetic lives in librt_amd.so (include/rt_hos
 scene prepared here is bit-identical to one prepared by the reference.  Index types are 32-bit
 (the reference's are 16-bit, src/index_types.hpp:8-11).
 """
+import ctypes
 import numpy as np
 
 from . import _lib
@@ -116,6 +117,27 @@ class Meshes:
         self.tris = np.concatenate(tris) if tris else np.zeros((0, 3), np.uint32)
         self.vertex_ranges = _u32(vranges, (-1, 2))
         self.tri_ranges = _u32(tranges, (-1, 2))
+
+
+def load_mesh(path):
+    """One Meshes entry (positions, normals, triangles) from a Wavefront OBJ or PLY file, read by
+    rt_mesh_load in librt_amd.so.  The reference itself only has literal meshes (src/main.cpp:25-121)."""
+    L = _lib.lib()
+    handle = ctypes.c_void_p()
+    if L.rt_mesh_load(str(path).encode(), ctypes.byref(handle)) != 0:
+        raise ValueError(L.rt_mesh_last_error().decode())
+    try:
+        nv, nt = ctypes.c_uint32(), ctypes.c_uint32()
+        L.rt_mesh_counts(handle, ctypes.byref(nv), ctypes.byref(nt))
+        pp, pn, pt = ctypes.POINTER(ctypes.c_float)(), ctypes.POINTER(ctypes.c_float)(), ctypes.POINTER(ctypes.c_uint32)()
+        L.rt_mesh_view(handle, ctypes.byref(pp), ctypes.byref(pn), ctypes.byref(pt))
+        def copy(ptr, count, dtype):
+            if count == 0:
+                return np.zeros((0, 3), dtype)
+            return np.ctypeslib.as_array(ptr, shape=(count, 3)).astype(dtype, copy=True)
+        return copy(pp, nv.value, np.float32), copy(pn, nv.value, np.float32), copy(pt, nt.value, np.uint32)
+    finally:
+        L.rt_mesh_destroy(handle)
 
 
 class Models:
