@@ -70,19 +70,6 @@ def cpu_baseline(scene, width, height, bounce_limit, target_seconds=12.0):
     out = {"value": st["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
            "sample": f"full {width}x{height} frame at {spp} spp ({st['segments']} segments in {dt:.2f} s)",
            "segments_per_path": st["segments"] / st["paths"]}
-    ref = binding.reference()
-    if ref is not None and scene.meshes.tris.max(initial=0) < 65536 and len(scene.models.meshes) < 65536:
-        # The compiled reference itself (src/render.hpp:53-212 inside the harness loop), same frame.
-        rsc = ref.scene_create(base_from_scene(scene), width, height)
-        try:
-            t0 = time.perf_counter()
-            rsc.render(spp, 1)
-            dtr = time.perf_counter() - t0
-        finally:
-            rsc.close()
-        out["reference_build_value"] = st["segments"] / dtr / 1e6
-        out["reference_build_note"] = ("oracle/_ref/libref.so, OpenMP over pixels, segments taken from the "
-                                       "port's count for the same number of paths")
     return out
 
 

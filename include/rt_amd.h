@@ -72,6 +72,10 @@ typedef struct {
      * {ndfAlphaSq, geometryAlphaSq, f0[3], adjustedColour[3], emission[3], 0} */
     const float* model_materials;
     uint32_t model_count;
+    /* Optional alternative to pretris: the same 12 floats per entry of leaf_refs (parallel array), which
+     * is what Leaf::tris holds in the reference (src/bsp.hpp:161-168); when non-null, pretris may be null
+     * (model_pretri_begin and pretri_count are still required: they number the triangles). */
+    const float* leaf_pretris;
 } rt_scene_desc;
 
 typedef struct rt_scene rt_scene;

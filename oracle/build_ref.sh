@@ -33,3 +33,19 @@ g++ "${flags[@]}" -E -I"$ref/src" -I"$ref/libraries/glm" "$here/ref_harness.cpp"
         -e 's/data\.m256i_u32\[/((std::uint32_t*)\&data)[/g' \
   | g++ "${flags[@]}" -x c++-cpp-output - -shared -o "$out/libref.so"
 echo "built $out/libref.so"
+
+# The reference program with render() bound to librt_amd.so (oracle/ref_dropin.cpp): same recipe, linked
+# against the product library, which it finds next to the repository's package at run time.
+lib="$here/../raytracing_amd"
+if [ -f "$lib/librt_amd.so" ]; then
+    g++ "${flags[@]}" -E -I"$ref/src" -I"$ref/libraries/glm" -I"$here/../include" "$here/ref_dropin.cpp" \
+      | sed -e 's/typedef IndexType IndexType;//' \
+            -e 's/typedef SizeType SizeType;//' \
+            -e 's/\(VertexRange\|TriRange\)::\(IndexType\|SizeType\)/std::uint32_t/g' \
+            -e 's/data\.m128_f32\[/((float*)\&data)[/g' \
+            -e 's/data\.m256_f32\[/((float*)\&data)[/g' \
+            -e 's/data\.m256i_u32\[/((std::uint32_t*)\&data)[/g' \
+      | g++ "${flags[@]}" -x c++-cpp-output - -o "$out/ref_main_gpu" -L"$lib" -lrt_amd \
+            -Wl,-rpath,'$ORIGIN/../../raytracing_amd' -Wl,-rpath-link,/opt/rocm/lib
+    echo "built $out/ref_main_gpu"
+fi

@@ -37,7 +37,7 @@ class RtSceneDesc(ctypes.Structure):
                 ("pretris", vp), ("model_pretri_begin", vp), ("pretri_count", c_u32),
                 ("vertex_normals", vp), ("model_vertex_begin", vp), ("vertex_count", c_u32),
                 ("base_tris", vp), ("model_tri_begin", vp), ("base_tri_count", c_u32),
-                ("model_materials", vp), ("model_count", c_u32)]
+                ("model_materials", vp), ("model_count", c_u32), ("leaf_pretris", vp)]
 
 
 class RtRenderParams(ctypes.Structure):

@@ -841,13 +841,13 @@ int rt_internal_fail(int code, const char* message) { return fail(code, message 
 extern "C" {
 
 const char* rt_last_error(void) { return g_lastError.c_str(); }
-uint32_t rt_abi_version(void) { return 2; }
+uint32_t rt_abi_version(void) { return 3; }
 
 int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     if (!D || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
     if (!D->model_pretri_begin || !D->model_vertex_begin || !D->leaf_first_ref)
         return fail(RT_ERR_INVALID, "rt_scene_create: null offset array in description");
-    if ((D->model_count && (!D->model_tri_begin || !D->model_materials)) || (D->pretri_count && !D->pretris)
+    if ((D->model_count && (!D->model_tri_begin || !D->model_materials)) || (D->pretri_count && !D->pretris && !D->leaf_pretris)
         || (D->vertex_count && !D->vertex_normals) || (D->base_tri_count && !D->base_tris))
         return fail(RT_ERR_INVALID, "rt_scene_create: null array in description");
     if (D->inode_count && !D->inodes) return fail(RT_ERR_INVALID, "rt_scene_create: inodes missing");
@@ -938,7 +938,8 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
         uint32_t const b = D->model_pretri_begin[ref.mesh], e = D->model_pretri_begin[ref.mesh + 1];
         if (ref.tri >= e - b) return fail(RT_ERR_INVALID, "rt_scene_create: leaf ref triangle out of range");
         uint32_t const gtri = b + ref.tri;
-        float const* pt = D->pretris + 12 * static_cast<size_t>(gtri);    // normal, v1, v1ToV3, v1ToV2
+        float const* pt = D->leaf_pretris ? D->leaf_pretris + 12 * static_cast<size_t>(r)
+                                          : D->pretris + 12 * static_cast<size_t>(gtri);    // normal, v1, v1ToV3, v1ToV2
         float* o = leafTris.data() + 16 * static_cast<size_t>(r);
         std::memcpy(o, pt, 48);
         uint32_t const ids[4] = {ref.mesh, ref.tri, gtri, 0u};

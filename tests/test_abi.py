@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported():
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.RtInode) == 60
     assert _lib.HIT_DTYPE.itemsize == 32 and _lib.TRI_REF_DTYPE.itemsize == 8
-    assert _lib.lib().rt_abi_version() == 2
+    assert _lib.lib().rt_abi_version() == 3
 
 
 def test_errors_are_reported_not_crashed():
@@ -49,3 +49,19 @@ def test_no_fallback_without_library(tmp_path, monkeypatch):
         raised = True
     assert raised
     importlib.reload(_lib)
+
+
+def test_cpp_example_fails_loudly_without_a_gpu(tmp_path):
+    """The C++ host layer has no CPU fallback either: without a HIP device the program stops with the
+    library's error message."""
+    import os
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "render_builtin")
+    if not os.path.exists(exe):
+        pytest.skip("examples/render_builtin not built")
+    run = subprocess.run([exe, "64", "48", "1", "1", str(tmp_path / "x.ppm")], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 1 and "no HIP device" in run.stderr
+    assert not (tmp_path / "x.ppm").exists()
