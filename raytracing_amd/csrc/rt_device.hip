@@ -246,7 +246,12 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     // warm, and no atomic is needed); the rest is handed out through the cursor so that no wave is left
     // holding a long tail.  An atomic on the one cursor costs several ns because they serialise.
     uint32_t const waves = gridDim.x * (RT_BLOCK / 64u);
-    uint32_t const waveId = blockIdx.x * (RT_BLOCK / 64u) + (threadIdx.x >> 6);
+    // Workgroups are handed to the eight XCDs in turn (workgroup b runs on XCD b mod 8).  Waves are numbered
+    // so that each XCD works on a contiguous eighth of every round of chunks: rays that are neighbours in
+    // the stream then share one XCD's L2 instead of being spread over all eight.
+    uint32_t const xcdBlocks = gridDim.x / 8u;
+    uint32_t const vblock = (gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * xcdBlocks + blockIdx.x / 8u : blockIdx.x;
+    uint32_t const waveId = vblock * (RT_BLOCK / 64u) + (threadIdx.x >> 6);
     uint32_t const staticRounds = static_cast<uint32_t>((static_cast<uint64_t>(n) * 3u / 4u) / (static_cast<uint64_t>(waves) * RT_FETCH_CHUNK));
     uint32_t const staticLines = staticRounds * waves * RT_FETCH_CHUNK;
     uint32_t staticRound = 0;

@@ -187,3 +187,8 @@ def dragon_scale_scene(target_tris=900_000, seed=1234, copies=1):
     dist = 4.2 * side
     camera = Camera((0.9 * dist, 0.75 * dist + 1.0, dist), (0.55, float(np.pi) + 0.72, 0.0), F(np.radians(45.0)))
     return Scene(camera, meshes, materials, m, inflate_mode=1)
+
+
+def multi_mesh_scene():
+    """BASELINE config 5: about 10 M triangles in eleven instances of the displaced surface, low-roughness GGX."""
+    return dragon_scale_scene(900_000, copies=11)

@@ -6,10 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import scenes
 from raytracing_amd.render import DeviceScene, RayTraceData
 
-def run(name, sc, w, h, spp, reps=3):
+def run(name, sc, w, h, spp, reps=3, bounce_limit=8):
+    t0 = time.time()
     sc.preprocess()
+    t1 = time.time()
     ds = DeviceScene(RayTraceData(sc))
-    p = ds.make_params(w, h, sc.camera.position, sc.pixel_to_ray_transform(w, h), spp=spp, flags=2)
+    print(f"{name}: {len(sc.preprocessed_tris.tris)} triangles, preprocess+tree {t1 - t0:.1f} s, upload {time.time() - t1:.1f} s, "
+          f"depth {ds.depth}, {ds.device_bytes / 1e9:.2f} GB on device", flush=True)
+    p = ds.make_params(w, h, sc.camera.position, sc.pixel_to_ray_transform(w, h), spp=spp, flags=2, bounce_limit=bounce_limit)
     ds.render(p)
     best = None
     for _ in range(reps):
@@ -27,3 +31,5 @@ if "builtin" in which: run("builtin", scenes.builtin_scene(), 1920, 1080, 16)
 if "cornell" in which: run("cornell", scenes.cornell_scene(), 1920, 1080, 16)
 if "dragon100k" in which: run("dragon100k", scenes.dragon_scale_scene(100_000), 1920, 1080, 16)
 if "dragon" in which: run("dragon900k", scenes.dragon_scale_scene(900_000), 1920, 1080, 16)
+# BASELINE config 5: eleven instances of the 0.9 M-triangle surface, low-roughness GGX, 12 bounces
+if "multi10m" in which: run("multi10m", scenes.dragon_scale_scene(900_000, copies=11), 1920, 1080, 8, reps=2, bounce_limit=12)
