@@ -152,8 +152,7 @@ int rt_postprocess(int device, const float* hdr, uint32_t width, uint32_t height
 
 /* Test hook: evaluates one scalar building block of the kernels on the GPU for n inputs so that its
  * bits can be pinned: op 0 a/b, 1 sqrt(a), 2 sin,cos(2*pi*a) (2 outputs), 3 Philox words (2 outputs),
- * 4 fma(a,b,a), 5 a*b+a unfused, 6 a/b through the reciprocal-based sequence the box test uses.  Not part of
- * the rendering interface. */
+ * 4 fma(a,b,a), 5 a*b+a unfused.  Not part of the rendering interface. */
 int rt_selftest_math(int op, const float* a, const float* b, uint32_t n, float* out);
 
 const char* rt_last_error(void);

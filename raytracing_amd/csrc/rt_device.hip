@@ -63,7 +63,6 @@ struct DevScene {
     const uint4* leafIds;
     const float4* triNormals;
     const float4* materials;
-    int fastDivision;      // every box plane coordinate is 0 or in [2^-75, 2^100): see divByRecip
     float boxAbsMax;       // largest |coordinate| of the root box: see filterMargin
 };
 
@@ -103,51 +102,26 @@ __device__ __forceinline__ V3 crossF(V3 a, V3 b) {
     return mk(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x)));
 }
 
-// Correctly rounded a/b from y = RN(1/b), without the hardware division sequence.
-//   q0 = RN(a*y); q1 = RN(q0 + (a - b*q0)*y) is a faithful quotient; one more correction step gives
-//   RN(a/b) for every rounding direction (Markstein, "Computation of elementary functions on the IBM
-//   RISC System/6000 processor", 1990: a faithful quotient corrected once with the correctly rounded
-//   reciprocal is correctly rounded).  The residuals a - b*q are exact FMA results as long as
-//   2^-100 <= |a| (or a == 0) and nothing overflows; callers guarantee that range (see RayRecips).
-__device__ __forceinline__ float divByRecip(float a, float b, float y) {
-    float const q0 = a * y;
-    float const q1 = __fmaf_rn(__fmaf_rn(-b, q0, a), y, q0);
-    return __fmaf_rn(__fmaf_rn(-b, q1, a), y, q1);
-}
-
 // One face of the reference's six-face box test (src/geometry.hpp:136-212): the line meets the face
 // plane at t = numer/denom with |denom| >= 1e-6 and t >= 0, and the point origin + t*direction
 // (unfused) lies inside the face rectangle, bounds inclusive.  Written without branches: the six faces
-// are evaluated by every lane and OR-ed, which is the same boolean as the reference's early-out chain
-// and keeps the 64 lanes of a wave in lock step.  EXACT_DIV selects the hardware division (any input
-// range) over divByRecip (inputs in the guarded range).
-template <bool EXACT_DIV>
-__device__ __forceinline__ bool faceHit(float denom, float recip, float numer, float oa, float da, float loa,
-                                        float hia, float ob, float db, float lob, float hib) {
-    float const t = EXACT_DIV ? numer / denom : divByRecip(numer, denom, recip);
+// are evaluated and OR-ed, which is the same boolean as the reference's early-out chain.
+__device__ __forceinline__ bool faceHit(float denom, float numer, float oa, float da, float loa, float hia, float ob,
+                                        float db, float lob, float hib) {
+    float const t = numer / denom;
     float const pa = oa + t * da;
     float const pb = ob + t * db;
     return (fabsf(denom) >= 1e-6f) & (t >= 0.0f) & (pa >= loa) & (pa <= hia) & (pb >= lob) & (pb <= hib);
 }
 
-// r = RN(1/d) per axis, computed once per line with true divisions.
-template <bool EXACT_DIV>
-__device__ __forceinline__ bool lineBox(V3 o, V3 d, V3 r, V3 lo, V3 hi) {
-    bool const a = faceHit<EXACT_DIV>(-d.x, -r.x, o.x - lo.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z);
-    bool const b = faceHit<EXACT_DIV>(d.x, r.x, hi.x - o.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z);
-    bool const c = faceHit<EXACT_DIV>(-d.y, -r.y, o.y - lo.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z);
-    bool const e = faceHit<EXACT_DIV>(d.y, r.y, hi.y - o.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z);
-    bool const f = faceHit<EXACT_DIV>(-d.z, -r.z, o.z - lo.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y);
-    bool const g = faceHit<EXACT_DIV>(d.z, r.z, hi.z - o.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y);
+__device__ __forceinline__ bool lineBox(V3 o, V3 d, V3 lo, V3 hi) {
+    bool const a = faceHit(-d.x, o.x - lo.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z);
+    bool const b = faceHit(d.x, hi.x - o.x, o.y, d.y, lo.y, hi.y, o.z, d.z, lo.z, hi.z);
+    bool const c = faceHit(-d.y, o.y - lo.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z);
+    bool const e = faceHit(d.y, hi.y - o.y, o.x, d.x, lo.x, hi.x, o.z, d.z, lo.z, hi.z);
+    bool const f = faceHit(-d.z, o.z - lo.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y);
+    bool const g = faceHit(d.z, hi.z - o.z, o.x, d.x, lo.x, hi.x, o.y, d.y, lo.y, hi.y);
     return a | b | c | e | f | g;
-}
-
-// divByRecip is exact for this line against every box of a scene whose plane coordinates c satisfy
-// c == 0 or 2^-75 <= |c| < 2^100 (checked on the host when the scene is created) if each origin
-// coordinate obeys the same bounds: then every numerator origin - c is zero or at least 2^-100.
-__device__ __forceinline__ bool coordInFastRange(float x) {
-    float const a = fabsf(x);
-    return (a == 0.0f) | ((a >= 0x1p-75f) & (a < 0x1p100f));
 }
 
 // ---- conservative filter in front of the six-face test ---------------------------------------------
@@ -175,8 +149,9 @@ __device__ __forceinline__ bool coordInFastRange(float x) {
 __device__ __forceinline__ float filterMargin(V3 o, V3 d, V3 r, float boxAbsMax) {
     float const m = 0x1p-20f * (boxAbsMax + fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)));
     float const dMin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    float const dMax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
     float const rMax = fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fabsf(r.z));
-    return dMin >= 0x1p-16f ? m * rMax : INFINITY;
+    return (dMin >= 0x1p-16f && dMax < INFINITY) ? m * rMax : INFINITY;      // false for NaN components too
 }
 
 // Bit 0: surely meets; bit 1: surely misses; bit 2: the exit face is clear of the other two slabs' far
@@ -197,15 +172,21 @@ __device__ __forceinline__ int boxFilter(V3 o, V3 r, float mu, V3 lo, V3 hi) {
     return (sureHit ? 1 : 0) | (sureMiss ? 2 : 0) | (exitClear ? 4 : 0);
 }
 
-// Origin-inside rule for pairs the filter left open (typically an origin lying exactly on a plane of
+// Origin-inside rules for pairs the filter left open (typically an origin lying exactly on a plane of
 // the box: a camera placed on a split plane of the tree, a path vertex on a wall that coincides with a
-// box face).  If the origin is inside the closed box (exact comparisons) and the exit face is clear of
-// the other slabs' far planes, the reference's test of the exit face succeeds: its t is a quotient of
-// two numbers of equal sign (or zero), hence >= 0; on the other axes the point o_b + t d_b has moved
-// from o_b towards the far plane, so rounding cannot take it back below the near plane
-// (RN(o_b + x) >= o_b for x >= 0), and it stays below the far plane by the margin exitClear provides.
-__device__ __forceinline__ bool originInsideRule(int filterBits, V3 o, V3 lo, V3 hi) {
-    return (filterBits & 4) != 0 && o.x >= lo.x && o.x <= hi.x && o.y >= lo.y && o.y <= hi.y && o.z >= lo.z && o.z <= hi.z;
+// box face).  The origin must be inside the closed box (exact comparisons), and either
+//   (a) it lies exactly on one of the box's planes: for that face the reference's numerator is an exact
+//       zero, so t = 0 (of either sign; t >= 0 holds) and the point it tests is o + 0*d = o itself, which
+//       is inside the face rectangle; or
+//   (b) the exit face is clear of the other slabs' far planes: the reference's t for that face is a
+//       quotient of two numbers of equal sign, hence >= 0; on the other axes the point o_b + t d_b has
+//       moved from o_b towards the far plane, so rounding cannot take it back below the near plane
+//       (RN(o_b + x) >= o_b for x >= 0), and it stays below the far plane by the margin exitClear provides.
+// Both need every |direction component| >= 1e-6 and finite, which mu < inf guarantees (filterMargin).
+__device__ __forceinline__ bool originInsideRule(int filterBits, float mu, V3 o, V3 lo, V3 hi) {
+    bool const inside = o.x >= lo.x && o.x <= hi.x && o.y >= lo.y && o.y <= hi.y && o.z >= lo.z && o.z <= hi.z;
+    bool const onPlane = o.x == lo.x || o.x == hi.x || o.y == lo.y || o.y == hi.y || o.z == lo.z || o.z == hi.z;
+    return inside && mu < INFINITY && (onPlane || (filterBits & 4) != 0);
 }
 
 struct HitRec {
@@ -264,7 +245,6 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     int sp = 0;
     V3 o = mk(0.0f, 0.0f, 0.0f), d = o, r = o;
     float mu = INFINITY;
-    bool fastDiv = false;
     HitRec best;
     best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
 
@@ -292,7 +272,6 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 line = chunkNext + rank;
                 load(line, o, d);
                 r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                fastDiv = S.fastDivision && coordInFastRange(o.x) && coordInFastRange(o.y) && coordInFastRange(o.z);
                 mu = filterMargin(o, d, r, S.boxAbsMax);
                 sp = 0; cur = 0;
                 pend1 = NONE; pend2 = NONE; pend3 = NONE;
@@ -323,9 +302,9 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             bool meets = (filterBits & 1) != 0;
             bool decided = (filterBits & 3) != 0;
             if (COUNT || !decided) {
-                if (!decided && originInsideRule(filterBits, o, nlo, nhi)) { meets = true; decided = true; }
+                if (!decided && originInsideRule(filterBits, mu, o, nlo, nhi)) { meets = true; decided = true; }
                 if (COUNT || !decided) {
-                    bool const exact = fastDiv ? lineBox<false>(o, d, r, nlo, nhi) : lineBox<true>(o, d, r, nlo, nhi);
+                    bool const exact = lineBox(o, d, nlo, nhi);
                     if (COUNT) {
                         if (!decided) c.boxFallbacks++;
                         else if (exact != meets) c.boxFilterErrors++;
@@ -777,7 +756,6 @@ __global__ void k_selftest(int op, const float* __restrict__ a, const float* __r
     }
     case 4: out[i] = __fmaf_rn(a[i], b[i], a[i]); break;
     case 5: out[i] = a[i] * b[i] + a[i]; break;          // must NOT be fused
-    case 6: out[i] = divByRecip(a[i], b[i], 1.0f / b[i]); break;
     default: out[i] = 0.0f;
     }
 }
@@ -829,7 +807,12 @@ int persistentGrid(rt_scene* s, Kernel kernel, uint64_t items) {
     if (perCu == 0) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, RT_BLOCK, 0) != hipSuccess || perCu <= 0) perCu = 4;
         if (std::getenv("RT_AMD_DEBUG")) std::fprintf(stderr, "rt_amd: persistent kernel %p: %d resident blocks per CU\n", key, perCu);
-        perCu = std::min(perCu, 8);
+        // Seven resident blocks (28 waves) per CU: measured best overall.  With eight, the 32 KB L1 of a
+        // CU is shared by more lines at once and its hit rate drops (-3 % on a 4 k-triangle scene, +0.4 %
+        // on a 0.9 M-triangle one); six or fewer lose latency hiding on the large scenes.
+        // RT_AMD_BLOCKS_PER_CU overrides the cap for tuning.
+        perCu = std::min(perCu, 7);
+        if (const char* cap = std::getenv("RT_AMD_BLOCKS_PER_CU")) perCu = std::max(1, std::min(8, std::atoi(cap)));
         s->occupancy.emplace_back(key, perCu);
     }
     uint64_t const blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
@@ -927,13 +910,6 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
             todo.push_back({pair, in.neg_index, it.depth + 1});
         }
     }
-    bool fastDivision = true;
-    for (HNode const& n : nodes)
-        for (int k = 0; k < 3; ++k)
-            for (float c : {n.lo[k], n.hi[k]}) {
-                float const a = std::fabs(c);
-                if (!(a == 0.0f || (a >= 0x1p-75f && a < 0x1p100f))) fastDivision = false;
-            }
     if (maxDepth > RT_STACK_MAX)
         return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth " + std::to_string(maxDepth) + " exceeds the "
                     + std::to_string(RT_STACK_MAX) + "-entry traversal stack");
@@ -1007,7 +983,6 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     s->dev.leafIds = static_cast<const uint4*>(s->dLeafIds);
     s->dev.triNormals = static_cast<const float4*>(s->dTriNormals);
     s->dev.materials = static_cast<const float4*>(s->dMaterials);
-    s->dev.fastDivision = fastDivision ? 1 : 0;
     s->dev.boxAbsMax = 0.0f;
     for (int k = 0; k < 3; ++k)
         s->dev.boxAbsMax = std::max(s->dev.boxAbsMax, std::max(std::fabs(nodes[0].lo[k]), std::fabs(nodes[0].hi[k])));

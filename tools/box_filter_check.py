@@ -20,7 +20,7 @@ def filter_decisions(o, d, lo, hi, mbox):
         r = (f32(1.0) / d).astype(f32)
         m = f32(2.0 ** -20) * (f32(mbox) + np.abs(o).max(axis=1)).astype(f32)
         rmax = np.abs(r).max(axis=1)
-        ok = np.abs(d).min(axis=1) >= f32(2.0 ** -16)
+        ok = (np.abs(d).min(axis=1) >= f32(2.0 ** -16)) & (np.abs(d).max(axis=1) < f32(np.inf))
         mu = np.where(ok, (m * rmax).astype(f32), f32(np.inf)).astype(f32)
         a = ((lo - o).astype(f32) * r).astype(f32)
         b = ((hi - o).astype(f32) * r).astype(f32)
@@ -35,7 +35,8 @@ def filter_decisions(o, d, lo, hi, mbox):
         sure_miss = (tX < -theta) | ((tE - tX).astype(f32) > theta2)
         # origin-inside rule, applied only to pairs still open
         inside = ((o >= lo) & (o <= hi)).all(axis=1)
-        sure_hit = sure_hit | (~sure_hit & ~sure_miss & exit_clear & inside)
+        on_plane = ((o == lo) | (o == hi)).any(axis=1)
+        sure_hit = sure_hit | (~sure_hit & ~sure_miss & inside & np.isfinite(mu) & (exit_clear | on_plane))
     return sure_hit, sure_miss
 
 
