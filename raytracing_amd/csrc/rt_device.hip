@@ -811,8 +811,9 @@ int persistentGrid(rt_scene* s, Kernel kernel, uint64_t items) {
         // CU is shared by more lines at once and its hit rate drops (-3 % on a 4 k-triangle scene, +0.4 %
         // on a 0.9 M-triangle one); six or fewer lose latency hiding on the large scenes.
         // RT_AMD_BLOCKS_PER_CU overrides the cap for tuning.
-        perCu = std::min(perCu, 7);
-        if (const char* cap = std::getenv("RT_AMD_BLOCKS_PER_CU")) perCu = std::max(1, std::min(8, std::atoi(cap)));
+        int cap = 7;
+        if (const char* text = std::getenv("RT_AMD_BLOCKS_PER_CU")) cap = std::max(1, std::atoi(text));
+        perCu = std::min(perCu, cap);
         s->occupancy.emplace_back(key, perCu);
     }
     uint64_t const blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
