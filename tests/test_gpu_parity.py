@@ -150,8 +150,8 @@ def test_intersect_edge_cases(builtin, builtin_oracle):
     sc, ds = builtin
     assert len(ds.intersect(np.zeros((0, 3)), np.zeros((0, 3)))) == 0                    # empty batch
     # axis-parallel, grazing and outward-pointing lines, origins on box faces and far outside
-    # (the last three origins have a coordinate below 2^-75, which sends the lane down the
-    # hardware-division path of the box test)
+    # (axis-parallel lines have a zero direction component, which the slab filter leaves entirely to
+    # the exact box test; the last three origins have denormal-range coordinates)
     o = np.array([[9, 8, 16], [0, 0.5, 0], [0, 0, 0], [-10.01, 5, 0], [100, 100, 100], [0, 20, 0], [2, 2.5, 2],
                   [0, 1e-3, 0], [1e-30, 5, 3], [3, 1e-38, -2], [-4, 6, -1e-45]], np.float32)
     d = np.array([[0, 1, 0], [1, 0, 0], [0, -1, 0], [1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 0, 1], [0.6, 0, 0.8],
