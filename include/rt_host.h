@@ -76,7 +76,8 @@ int rt_tri_intersects_box(const float tri[9], const float box[6]);
  * ascending (model, triangle) order) but visits only each node's candidate triangles instead of
  * rescanning the whole scene.  Where the reference would recurse without bound (more than
  * max_leaf_tris triangles meeting in an arbitrarily small box) the builder stops at max_depth and
- * emits an oversized leaf. */
+ * emits an oversized leaf.  threads > 1 builds subtrees in parallel and restores the sequential order
+ * afterwards (same arrays, bit for bit); threads <= 0 picks OMP_NUM_THREADS or up to 16 hardware threads. */
 typedef struct rt_bsp rt_bsp;
 int rt_bsp_build(const float* inst_positions, const uint32_t* model_vertex_begin, const uint32_t* base_tris,
                  const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,

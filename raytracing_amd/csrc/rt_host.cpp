@@ -6,8 +6,11 @@
 #include "rt_host.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -316,7 +319,23 @@ struct Builder {
     // That keeps the result identical to the reference, which re-tests every triangle of the scene
     // against every node box (src/bsp.hpp:188-211), even if rounding made the exact predicate
     // non-monotonic between a box and its half.
+    //
+    // With `tasks` set, subtrees at depth `cutDepth` or below whose candidate list has shrunk to `taskMax`
+    // (a fraction of the scene per worker, so that unevenly filled space still balances) are not built:
+    // their inputs are recorded and the returned index is a placeholder (TASK_BASE + task number); they
+    // are built independently afterwards and spliced in by Stitcher.
+    struct Task { Box box; std::vector<uint32_t> cand; int axis; uint32_t depth; };
+    static constexpr int32_t TASK_BASE = 0x40000000;
+    std::vector<Task>* tasks = nullptr;
+    uint32_t cutDepth = 0;
+    size_t taskMax = 0;
+
     int32_t node(Box const& box, std::vector<uint32_t> const& cand, int axis, uint32_t depth) {
+        if (tasks && depth >= cutDepth && cand.size() > 4 * static_cast<size_t>(maxLeaf)
+            && (cand.size() <= taskMax || depth >= cutDepth + 12)) {
+            tasks->push_back(Task{box, cand, axis, depth});
+            return TASK_BASE + static_cast<int32_t>(tasks->size() - 1);
+        }
         out.depth = std::max(out.depth, depth);
         std::vector<uint32_t> inside;
         inside.reserve(std::min<size_t>(cand.size(), maxLeaf + 1));
@@ -366,6 +385,53 @@ struct Builder {
     }
 };
 
+// Re-emits the top of the tree in the order the sequential build would have produced (interior nodes in
+// pre-order, negative side first; leaves in creation order) and splices the independently built
+// subtrees in where their placeholders stand, shifting their node and leaf numbers.
+struct Stitcher {
+    rt_bsp const& top;
+    std::vector<rt_bsp> const& parts;
+    rt_bsp& out;
+
+    void appendLeaf(rt_bsp const& src, uint32_t leaf) {            // leaf numbers are 1-based (index = -leaf)
+        for (uint32_t r = src.leaf_first[leaf - 1]; r < src.leaf_first[leaf]; ++r) out.refs.push_back(src.refs[r]);
+        out.leaf_first.push_back(static_cast<uint32_t>(out.refs.size()));
+    }
+
+    int32_t splice(rt_bsp const& part) {
+        int32_t const inodeShift = static_cast<int32_t>(out.inodes.size());
+        int32_t const leafShift = static_cast<int32_t>(out.leaf_first.size() - 1);
+        auto shifted = [&](int32_t index) { return index > 0 ? index + inodeShift : (index < 0 ? index - leafShift : 0); };
+        for (rt_inode n : part.inodes) {
+            n.neg_index = shifted(n.neg_index);
+            n.pos_index = shifted(n.pos_index);
+            out.inodes.push_back(n);
+        }
+        uint32_t const refShift = static_cast<uint32_t>(out.refs.size());
+        out.refs.insert(out.refs.end(), part.refs.begin(), part.refs.end());
+        for (size_t l = 1; l < part.leaf_first.size(); ++l) out.leaf_first.push_back(part.leaf_first[l] + refShift);
+        out.depth = std::max(out.depth, part.depth);
+        out.oversized += part.oversized;
+        return shifted(part.root_index);
+    }
+
+    int32_t emit(int32_t index) {
+        if (index == 0) return 0;
+        if (index >= Builder::TASK_BASE) return splice(parts[static_cast<size_t>(index - Builder::TASK_BASE)]);
+        if (index < 0) {
+            appendLeaf(top, static_cast<uint32_t>(-index));
+            return -static_cast<int32_t>(out.leaf_first.size() - 1);
+        }
+        size_t const self = out.inodes.size();
+        out.inodes.push_back(top.inodes[static_cast<size_t>(index - 1)]);
+        int32_t const neg = emit(top.inodes[static_cast<size_t>(index - 1)].neg_index);
+        int32_t const pos = emit(top.inodes[static_cast<size_t>(index - 1)].pos_index);
+        out.inodes[self].neg_index = neg;
+        out.inodes[self].pos_index = pos;
+        return static_cast<int32_t>(self + 1);
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -381,7 +447,6 @@ int rt_tri_intersects_box(const float tri[9], const float box[6]) {
 int rt_bsp_build(const float* inst_positions, const uint32_t* model_vertex_begin, const uint32_t* base_tris,
                  const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,
                  const float root_box[6], uint32_t max_leaf_tris, uint32_t max_depth, int threads, rt_bsp** out) {
-    (void)threads;
     if (!inst_positions || !model_vertex_begin || !base_tris || !mesh_tri_ranges || !model_meshes || !root_box || !out
         || max_leaf_tris == 0) return RT_ERR_INVALID;
     rt_bsp* bsp = new (std::nothrow) rt_bsp;
@@ -418,8 +483,61 @@ int rt_bsp_build(const float* inst_positions, const uint32_t* model_vertex_begin
         // The exact predicate's first three axes compare translated coordinates whose rounding
         // error is a few ulps of the scene's coordinate magnitude; 1e-4 of that magnitude is far
         // outside it, so no triangle that the exact test would accept is ever filtered out.
-        Builder b{tris, *bsp, max_leaf_tris, max_depth, 1e-4f * scale};
-        bsp->root_index = b.node(Box{load3(root_box), load3(root_box + 3)}, all, 0, 0);
+        float const slack = 1e-4f * scale;
+        // threads <= 0: OMP_NUM_THREADS if set (the usual statement of a process's CPU share), else the
+        // hardware concurrency, capped at 16.
+        unsigned workers = threads > 0 ? static_cast<unsigned>(threads) : 0u;
+        if (workers == 0) {
+            if (const char* env = std::getenv("OMP_NUM_THREADS")) workers = static_cast<unsigned>(std::max(0, std::atoi(env)));
+            if (workers == 0) workers = std::min(std::thread::hardware_concurrency(), 16u);
+        }
+        workers = std::max(1u, std::min(workers, 64u));
+        if (workers == 1 || tris.size() < 200000) {
+            Builder b{tris, *bsp, max_leaf_tris, max_depth, slack};
+            bsp->root_index = b.node(Box{load3(root_box), load3(root_box + 3)}, all, 0, 0);
+        }
+        else {
+            // Top of the tree on this thread, down to subtrees holding at most 1/(8 workers) of the scene;
+            // the subtrees in parallel, largest first; then one pass that restores the sequential order.
+            uint32_t cut = 2;
+            while ((1u << cut) < workers && cut < 8) ++cut;
+            rt_bsp top;
+            top.leaf_first.push_back(0);
+            std::vector<Builder::Task> tasks;
+            Builder tb{tris, top, max_leaf_tris, max_depth, slack};
+            tb.tasks = &tasks;
+            tb.cutDepth = std::min(cut, max_depth);
+            tb.taskMax = std::max<size_t>(tris.size() / (8 * static_cast<size_t>(workers)), 1024);
+            top.root_index = tb.node(Box{load3(root_box), load3(root_box + 3)}, all, 0, 0);
+            std::vector<uint32_t>().swap(all);
+            std::vector<rt_bsp> parts(tasks.size());
+            std::vector<size_t> order(tasks.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tasks[a].cand.size() > tasks[b].cand.size(); });
+            std::atomic<size_t> next{0};
+            std::atomic<bool> failed{false};
+            auto work = [&]() {
+                try {
+                    for (size_t k = next.fetch_add(1); k < order.size(); k = next.fetch_add(1)) {
+                        size_t const i = order[k];
+                        parts[i].leaf_first.push_back(0);
+                        Builder pb{tris, parts[i], max_leaf_tris, max_depth, slack};
+                        parts[i].root_index = pb.node(tasks[i].box, tasks[i].cand, tasks[i].axis, tasks[i].depth);
+                        std::vector<uint32_t>().swap(tasks[i].cand);
+                    }
+                }
+                catch (std::bad_alloc const&) { failed = true; }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+            if (failed) throw std::bad_alloc();
+            bsp->depth = top.depth;
+            bsp->oversized = top.oversized;
+            Stitcher st{top, parts, *bsp};
+            bsp->root_index = st.emit(top.root_index);
+        }
     }
     catch (std::bad_alloc const&) {
         delete bsp;

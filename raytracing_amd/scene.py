@@ -219,13 +219,13 @@ class BSPTree:
     MAX_TRIS = 32       # Leaf::MAX_TRIS, src/bsp.hpp:162
 
     def __init__(self, inst_positions, vertex_begin, tris, tri_ranges, instance_meshes, box, max_leaf_tris=32,
-                 max_depth=60):
+                 max_depth=60, threads=0):
         L = _lib.lib()
         h = _lib.vp()
         mm = _u32(instance_meshes)
         _lib.check(L.rt_bsp_build(ptr(_f32(inst_positions)), ptr(_u32(vertex_begin)), ptr(_u32(tris)),
                                   ptr(_u32(tri_ranges, (-1, 2))), ptr(mm), c_u32(len(mm)), ptr(_f32(box, (6,))),
-                                  c_u32(max_leaf_tris), c_u32(max_depth), c_int(0), _lib.ctypes.byref(h)))
+                                  c_u32(max_leaf_tris), c_u32(max_depth), c_int(threads), _lib.ctypes.byref(h)))
         try:
             counts = np.zeros(5, np.uint32)
             L.rt_bsp_counts(h, ptr(counts))
@@ -262,7 +262,7 @@ class Scene:
         self.bounding_box = None
         self.bsp_tree = None
 
-    def preprocess(self, max_leaf_tris=32, max_depth=60):
+    def preprocess(self, max_leaf_tris=32, max_depth=60, threads=0):
         self.preprocessed_materials = np.stack([preprocess_material(m) for m in self.materials])
         self.instantiated_meshes = instantiate_meshes(self.meshes.vertex_positions, self.meshes.vertex_normals,
                                                       self.meshes.vertex_ranges, self.models.mesh_transforms,
@@ -272,7 +272,7 @@ class Scene:
                                                  self.meshes.tri_ranges, self.models.meshes)
         self.bounding_box = scene_bounding_box(im.vertex_positions, self.inflate_mode)
         self.bsp_tree = BSPTree(im.vertex_positions, im.vertex_begin, self.meshes.tris, self.meshes.tri_ranges,
-                                self.models.meshes, self.bounding_box, max_leaf_tris, max_depth)
+                                self.models.meshes, self.bounding_box, max_leaf_tris, max_depth, threads)
         return self
 
     def pixel_to_ray_transform(self, width, height):

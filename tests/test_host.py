@@ -169,3 +169,17 @@ def test_ppm_writer_matches_reference_file_layout(tmp_path):
     assert path.read_bytes() == b"P6\n7 5\n255\n" + rgb.tobytes()
     with pytest.raises(OSError):
         image.write_ppm(tmp_path / "missing_dir" / "x.ppm", rgb)
+
+
+@pytest.mark.parametrize("threads", [2, 5, 8])
+def test_threaded_build_restores_sequential_order(threads):
+    """Subtrees built in parallel and spliced back must give the arrays of the single-threaded build, bit
+    for bit: interior nodes in pre-order, leaves in creation order, references in ascending order."""
+    sc = scenes.dragon_scale_scene(target_tris=260_000)
+    one = sc.preprocess(threads=1).bsp_tree
+    a = tree_arrays(one)
+    many = sc.preprocess(threads=threads).bsp_tree
+    b = tree_arrays(many)
+    assert (one.depth, one.inode_count, one.leaf_count, one.ref_count) == (many.depth, many.inode_count, many.leaf_count, many.ref_count)
+    for k in a:
+        assert same_bits(a[k], b[k]), k
