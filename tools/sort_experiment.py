@@ -52,7 +52,7 @@ def run(name, sc, w=1920, h=1080):
     perm = rng.permutation(n)
     timeit(o1[perm], d1[perm], "secondary, random order")
     octant = ((d1[:, 0] > 0).astype(np.uint64) | (d1[:, 1] > 0).astype(np.uint64) << 1 | (d1[:, 2] > 0).astype(np.uint64) << 2)
-    for bits in (4, 6):
+    for bits in (4, 6, 8):
         G = 1 << bits
         q = np.clip(((o1 - box[:3]) / (box[3:] - box[:3]) * G).astype(np.int64), 0, G - 1)
         mort = morton3(q[:, 0], q[:, 1], q[:, 2], bits)
@@ -67,3 +67,5 @@ which = sys.argv[1:] or ["cornell", "builtin", "dragon100k"]
 if "cornell" in which: run("cornell", scenes.cornell_scene())
 if "builtin" in which: run("builtin", scenes.builtin_scene())
 if "dragon100k" in which: run("dragon100k", scenes.dragon_scale_scene(100_000))
+if "dragon" in which: run("dragon900k", scenes.dragon_scale_scene(900_000))
+if "multi" in which: run("multi10m", scenes.multi_mesh_scene())
