@@ -37,6 +37,8 @@ WORKLOADS = {
                 "reference built-in scene (src/main.cpp:134-187), 640x480, 16 spp, 8 bounces"),
     "dragon": ("dragon_scale_scene", 1920, 1080, 256, 8,
                "displaced closed surface, ~0.9M triangles (dragon-scale stand-in), 1920x1080, 256 spp, 8 bounces"),
+    "dragon4k": ("dragon_scale_scene", 3840, 2160, 128, 8,
+                 "displaced closed surface, ~0.9M triangles, 3840x2160, 128 spp per GPU (1024 spp on 8 GPUs), 8 bounces"),
     "multi": ("multi_mesh_scene", 1920, 1080, 64, 12,
               "eleven instances of the 0.9M-triangle surface (~9.9M triangles), GGX roughness 0.04-0.1, 1920x1080, "
               "64 spp, 12 bounces"),
