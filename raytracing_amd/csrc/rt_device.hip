@@ -201,12 +201,15 @@ struct HitRec {
 // test are those of the reference.
 //
 // Shape: persistent "while-while" with refill.  Each lane alternates between (1) walking interior
-// nodes until it stands on a leaf whose box its line meets and (2) testing that leaf's triangles;
-// lanes of a wave that reach a leaf early wait for the others so that phase 2 runs with most lanes
-// active.  A lane whose line is finished stores the result and takes the next line of the stream at
-// the top of the loop, so a wave is not held hostage by its longest line.  Lines are handed out in
-// chunks of RT_FETCH_CHUNK per wave (one global atomic per chunk); inside a chunk lanes take lines by
-// their rank among the idle lanes.
+// nodes until it stands on a leaf whose box its line meets and (2) testing that leaf's triangles; the
+// wave runs the two phases in turn so that each runs with most lanes active, and a lane that has found
+// its leaf before the others looks ahead for the next ones instead of idling.  A lane whose line is
+// finished stores the result and takes the next line of the stream at the top of the loop, so a wave
+// is not held hostage by its longest line.  Lines are handed out in chunks of RT_FETCH_CHUNK per wave
+// (dealt statically for most of the stream, through one atomic cursor for its tail); inside a chunk
+// lanes take lines by their rank among the idle lanes.
+// The stack accesses are written out inline on purpose: wrapping them in by-reference lambdas made the
+// compiler turn the wave-uniform exit of the outer loop into a divergent one, at a cost of 27 %.
 //   load(i, o, d)        reads line i of the stream
 //   store(i, hit, o, d)  receives its nearest hit (hit.ref == 0xFFFFFFFF: none)
 #define RT_FETCH_CHUNK 64u
