@@ -102,10 +102,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # Rehearsal on a box with fewer GPUs than ranks (RT_BENCH_SHARE_GPU=1): every rank renders on GPU 0 and
+    # the bands are gathered over gloo through host memory.  The numbers of such a run mean nothing; it
+    # exists to exercise the multi-rank code path.
+    share_gpu = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     _, width, height, spp1, bounce_limit, description = WORKLOADS[args.workload]
     spp1 = args.spp or spp1
@@ -123,7 +132,11 @@ def main():
                                seed=seed, rect=(x0, y0, w, h), flags=flags)
             return ds.render_device(p, out, stream=stream)
         st = tiles.render_sharded(render_rect, width, height, rank, world, buf, bands_per_rank)
-        frame = tiles.gather_frame(buf, width, height, rank, world, bands_per_rank, dist)
+        if share_gpu and world > 1:
+            torch.cuda.synchronize()
+            frame = tiles.gather_frame(buf.cpu(), width, height, rank, world, bands_per_rank, dist)
+        else:
+            frame = tiles.gather_frame(buf, width, height, rank, world, bands_per_rank, dist)
         return st, frame
 
     def fence():
@@ -150,7 +163,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([dt, float(seg)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(seg)], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

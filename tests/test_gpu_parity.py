@@ -467,3 +467,28 @@ def test_cpp_host_layer_program_matches_python_path(tmp_path):
         ds.close()
     assert np.array_equal(theirs, image.postprocess(hdr.reshape(270, 480, 3)))
     assert theirs.std() > 10
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """bench.py's multi-rank path (bands per rank, gather, max-over-ranks timing, one JSON line from rank 0)
+    with two ranks sharing this box's GPU and gloo as the transport (RT_BENCH_SHARE_GPU=1).  The rate it
+    prints means nothing; the code path is what the 2/4/8-GPU runs use with RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RT_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "2",
+           "--workload", "builtin"]
+    run = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["spp_total"] == 4 and out["config"]["image_finite"] is True
+    assert "cpu_baseline" not in out                         # N=1 only
+    # both ranks together traced the whole frame: 640x480 pixels x 4 spp paths
+    assert out["config"]["segments_per_step"] > 640 * 480 * 4
