@@ -123,7 +123,7 @@ def main():
     ds = DeviceScene(RayTraceData(scene), device=local_rank)
     p2r = scene.pixel_to_ray_transform(width, height)
     stream = torch.cuda.current_stream().cuda_stream
-    bands_per_rank = 4
+    bands_per_rank = 8          # tools/band_balance.py: max/mean rank load 1.03 at 8 ranks on the 0.9M-triangle scene (1.07 with 4)
     buf = torch.zeros(tiles.max_rank_rows(height, world, bands_per_rank) * width * 3, dtype=torch.float32, device="cuda")
 
     def step(seed, flags):
