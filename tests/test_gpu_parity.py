@@ -492,3 +492,41 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert "cpu_baseline" not in out                         # N=1 only
     # both ranks together traced the whole frame: 640x480 pixels x 4 spp paths
     assert out["config"]["segments_per_step"] > 640 * 480 * 4
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, (0, 0, 0)), (1e-3, (0, 0, 0)), (0.05, (0, 0, 0)), (3e3, (0, 0, 0)),
+                                          (1.0, (500, -200, 1000)), (0.02, (7, 7, 7))])
+def test_random_soups_at_many_scales_bit_exact(oracle_lib, scale, offset):
+    """Random triangle soups (nothing axis-aligned, several instances) at scene sizes from millimetres to
+    kilometres and far from the origin: the slab filter's margins scale with the coordinates, and hits,
+    rendered radiance and every work counter must still equal the oracle's.  (At the millimetre scale the
+    reference's absolute threshold |normal . direction| >= 1e-6, src/geometry.hpp:131, rejects every triangle:
+    the cross-product normal of a 0.3 mm triangle is about 1e-7 long.  Nothing is hit, by either side.)"""
+    rng = np.random.default_rng(int(scale * 1000) + int(offset[0]))
+    n = 2500
+    centres = rng.uniform(-4, 4, (n, 1, 3))
+    pos = ((centres + rng.uniform(-0.3, 0.3, (n, 3, 3))).reshape(-1, 3) * scale).astype(np.float32)
+    nrm = rng.standard_normal((len(pos), 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    tris = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    m = S.Models()
+    off = np.array(offset, np.float64) * scale
+    m.add(S.MeshTransform(tuple(off), S.IDENTITY_QUAT, (1, 1, 1)), 0, 0)
+    m.add(S.MeshTransform(tuple(off + np.array([0.3, 0.1, -0.2]) * scale), (0.2, 0.4, 0.1), (1.0, 0.7, 1.2)), 0, 1)
+    cam = S.Camera(tuple(off + np.array([0, 0, 14.0]) * scale), (0, np.pi, 0), 0.7)
+    mats = [S.Material((0.6, 0.5, 0.4), 0.4, 0.2, (0.5, 0.4, 0.3)), S.Material((0.9, 0.9, 0.9), 0.1, 0.9)]
+    sc = S.Scene(cam, S.Meshes([(pos, nrm, tris)]), mats, m, inflate_mode=1)
+    ds, osc = _pair(oracle_lib, sc, 96, 64)
+    try:
+        box = sc.bounding_box
+        o = rng.uniform(box[:3] - 0.2 * (box[3:] - box[:3]), box[3:] + 0.2 * (box[3:] - box[:3]), (20000, 3)).astype(np.float32)
+        d = rng.standard_normal((20000, 3))
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        for front in (True, False):
+            f, ids = osc.intersect(o, d, 1e-3 * scale, front)
+            _check_hits(ds.intersect(o, d, 1e-3 * scale, front), f, ids)
+        assert (ids[:, 0] != 0xFFFFFFFF).mean() > (0.05 if scale >= 0.02 else -1)
+        img, st, oimg, ost = _render_both(ds, osc, sc, 96, 64, spp=3, seed=9)
+        _assert_same_image_and_work(img, st, oimg, ost)
+    finally:
+        ds.close(); osc.close()
