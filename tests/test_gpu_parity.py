@@ -467,6 +467,16 @@ def test_cpp_host_layer_program_matches_python_path(tmp_path):
         ds.close()
     assert np.array_equal(theirs, image.postprocess(hdr.reshape(270, 480, 3)))
     assert theirs.std() > 10
+    # the same program with the cube read from an OBJ file (rt::loadMesh): a tetrahedron instead of the cube
+    obj = tmp_path / "tetra.obj"
+    obj.write_text("v -0.5 -0.5 -0.5\nv 0.5 -0.5 -0.5\nv 0 -0.5 0.5\nv 0 0.5 0\nf 1 2 3\nf 1 4 2\nf 2 4 3\nf 3 4 1\n")
+    out2 = tmp_path / "tetra.ppm"
+    run = subprocess.run([exe, "480", "270", "4", "11", str(out2), str(obj)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    other = np.frombuffer(out2.read_bytes(), np.uint8, offset=len(header)).reshape(270, 480, 3)
+    assert other.std() > 10 and not np.array_equal(other, theirs)
+    run = subprocess.run([exe, "480", "270", "4", "11", str(out2), str(tmp_path / "missing.obj")], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 1 and "cannot read" in run.stderr
 
 
 def test_bench_two_rank_rehearsal_on_one_gpu():
