@@ -190,5 +190,5 @@ def dragon_scale_scene(target_tris=900_000, seed=1234, copies=1):
 
 
 def multi_mesh_scene():
-    """BASELINE config 5: about 10 M triangles in eleven instances of the displaced surface, low-roughness GGX."""
+    """The multi-mesh benchmark scene: about 10 M triangles in eleven instances of the displaced surface, low-roughness GGX."""
     return dragon_scale_scene(900_000, copies=11)

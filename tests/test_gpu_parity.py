@@ -348,7 +348,7 @@ def test_full_hd_properties(builtin):
 
 
 def test_dragon_scale_scene_full_size(oracle_lib):
-    """BASELINE config 3: about 0.9 M triangles.  The reference's own tree build is O(nodes x triangles)
+    """The dragon-scale benchmark scene, about 0.9 M triangles.  The reference's own tree build is O(nodes x triangles)
     and cannot produce this tree in any reasonable time, so the oracle traverses the tree made by the
     product's builder (whose equality with the reference algorithm is established on small scenes in
     tests/test_host.py); hits and a rendered tile must still agree bit for bit, and the frame must not

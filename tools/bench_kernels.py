@@ -31,5 +31,5 @@ if "builtin" in which: run("builtin", scenes.builtin_scene(), 1920, 1080, 16)
 if "cornell" in which: run("cornell", scenes.cornell_scene(), 1920, 1080, 16)
 if "dragon100k" in which: run("dragon100k", scenes.dragon_scale_scene(100_000), 1920, 1080, 16)
 if "dragon" in which: run("dragon900k", scenes.dragon_scale_scene(900_000), 1920, 1080, 16)
-# BASELINE config 5: eleven instances of the 0.9 M-triangle surface, low-roughness GGX, 12 bounces
+# the multi-mesh benchmark scene: eleven instances of the 0.9 M-triangle surface, low-roughness GGX, 12 bounces
 if "multi10m" in which: run("multi10m", scenes.dragon_scale_scene(900_000, copies=11), 1920, 1080, 8, reps=2, bounce_limit=12)
