@@ -10,7 +10,9 @@
  * negative rt_status otherwise; rt_last_error() gives the message for the calling thread.
  *
  * Threading: a scene handle may be used by one host thread at a time; use one handle per GPU.
- * All "device" pointers are HIP device pointers on the scene's GPU.
+ * All "device" pointers are HIP device pointers on the scene's GPU.  Every call on a handle shares the
+ * handle's workspace: a call that arrives on a different hip_stream than the previous one first waits
+ * for that previous stream.
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H
@@ -90,6 +92,11 @@ typedef struct {
 
 #define RT_FLAG_COUNT_WORK      1u   /* fill the work counters of rt_stats (slower kernels) */
 #define RT_FLAG_PROFILE_KERNELS 2u   /* time every kernel launch with HIP events (adds syncs at the end) */
+/* Russian roulette, an estimator extension the reference does not have (its paths end only at the bounce
+ * limit, src/render.hpp:117): from the third bounce on a path survives with probability
+ * p = min(1, largest throughput component), drawn from the bounce's own Philox block, and its throughput
+ * is divided by p.  The converged image is unchanged; fewer long paths are traced. */
+#define RT_FLAG_RUSSIAN_ROULETTE 4u
 
 /* RenderData (src/render.hpp:38-44) + the compile-time constants of src/render.hpp:47-49 made
  * run-time, + a tile rectangle for multi-GPU sharding. */

@@ -61,6 +61,7 @@ class RtStats(ctypes.Structure):
 
 RT_FLAG_COUNT_WORK = 1
 RT_FLAG_PROFILE_KERNELS = 2
+RT_FLAG_RUSSIAN_ROULETTE = 4
 
 # Every symbol declared by include/rt_amd.h and include/rt_host.h.
 DEVICE_SYMBOLS = ["rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_intersect", "rt_intersect_device",

@@ -16,6 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -79,6 +82,7 @@ struct RenderConst {
     uint32_t bounceLimit;
     float tMin;
     uint32_t key0, key1;
+    uint32_t roulette;          // RT_FLAG_RUSSIAN_ROULETTE
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -429,7 +433,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
 
 // Philox-4x32-10 keyed by the render seed; counter = (pixel index, sample index, dimension pair, 0).
 __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1, uint32_t& r0,
-                                       uint32_t& r1) {
+                                       uint32_t& r1, uint32_t& r2) {
     uint32_t c3 = 0;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -439,7 +443,7 @@ __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, ui
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    r0 = c0; r1 = c1;
+    r0 = c0; r1 = c1; r2 = c2;
 }
 __device__ __forceinline__ float unitFloat(uint32_t v) { return static_cast<float>(v >> 8) * 0x1p-24f; }
 
@@ -535,8 +539,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P,
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < paths; id += stride) {
         uint32_t const sLocal = id / pixels, p = id - sLocal * pixels;
         uint32_t const px = R.x0 + p % R.w, py = R.y0 + p / R.w;
-        uint32_t r0, r1;
-        philox(py * R.width + px, sampleBase + sLocal, 0u, R.key0, R.key1, r0, r1);
+        uint32_t r0, r1, r2;
+        philox(py * R.width + px, sampleBase + sLocal, 0u, R.key0, R.key1, r0, r1, r2);
         float const sx = static_cast<float>(px) + unitFloat(r0);
         float const sy = static_cast<float>(py) + unitFloat(r1);
         V3 const v = mk(R.m[0] * sx + R.m[3] * sy + R.m[6] * 1.0f, R.m[1] * sx + R.m[4] * sy + R.m[7] * 1.0f,
@@ -634,8 +638,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
                     // GGX sampling of the half vector, src/render.hpp:145-153
                     uint32_t const sLocal = slot / pixels, p = slot - sLocal * pixels;
                     uint32_t const px = R.x0 + p % R.w, py = R.y0 + p / R.w;
-                    uint32_t r0, r1;
-                    philox(py * R.width + px, sampleBase + sLocal, bounce + 1u, R.key0, R.key1, r0, r1);
+                    uint32_t r0, r1, r2;
+                    philox(py * R.width + px, sampleBase + sLocal, bounce + 1u, R.key0, R.key1, r0, r1, r2);
                     float const thetaParam = unitFloat(r0);
                     float const cosThetaSq = 1.0f / (1.0f + ndfA * thetaParam / (1.0f - thetaParam));
                     float const cosTheta = sqrtf(cosThetaSq);
@@ -671,10 +675,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
                         V3 const spec = nDotO > 0.0f ? mk(F.x * sScale, F.y * sScale, F.z * sScale) : mk(0.0f, 0.0f, 0.0f);
                         V3 const w = diffuse + spec;
                         T = mk(w.x * T.x, w.y * T.y, w.z * T.z);                 // src/render.hpp:200-202
-                        V3 const point = mk(o.x + H.x * d.x, o.y + H.x * d.y, o.z + H.x * d.z);
-                        P.A[slot] = make_float4(point.x, point.y, point.z, incident.x);
-                        P.B[slot] = make_float4(incident.y, incident.z, T.x, T.y);
                         alive = true;
+                        // Russian roulette (no counterpart in the reference, whose paths end only at the bounce
+                        // limit, src/render.hpp:117): from the third bounce on a path survives with probability
+                        // p = min(1, largest throughput component) and its throughput is divided by p, which
+                        // leaves the expectation of every later contribution unchanged.
+                        if (R.roulette != 0u && bounce >= 2u) {
+                            float big = T.x;
+                            if (T.y > big) big = T.y;
+                            if (T.z > big) big = T.z;
+                            float const survive = big < 1.0f ? big : 1.0f;
+                            if (unitFloat(r2) >= survive) alive = false;
+                            else T = mk(T.x / survive, T.y / survive, T.z / survive);
+                        }
+                        if (alive) {
+                            V3 const point = mk(o.x + H.x * d.x, o.y + H.x * d.y, o.z + H.x * d.z);
+                            P.A[slot] = make_float4(point.x, point.y, point.z, incident.x);
+                            P.B[slot] = make_float4(incident.y, incident.z, T.x, T.y);
+                        }
                     }
                 }
                 C = make_float4(T.z, L.x, L.y, L.z);
@@ -752,8 +770,8 @@ __global__ void k_selftest(int op, const float* __restrict__ a, const float* __r
     case 1: out[i] = sqrtf(a[i]); break;
     case 2: { float s, c; sincos2pi(a[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break; }
     case 3: {
-        uint32_t r0, r1;
-        philox(__float_as_uint(a[i]), __float_as_uint(b[i]), 7u, 0x5EEDu, 0x1234u, r0, r1);
+        uint32_t r0, r1, r2;
+        philox(__float_as_uint(a[i]), __float_as_uint(b[i]), 7u, 0x5EEDu, 0x1234u, r0, r1, r2);
         out[2 * i] = __uint_as_float(r0); out[2 * i + 1] = __uint_as_float(r1);
         break;
     }
@@ -769,6 +787,16 @@ __global__ void k_selftest(int op, const float* __restrict__ a, const float* __r
 // Host side of the C ABI
 // ------------------------------------------------------------------------------------------------
 
+// Path-state buffers of one render call, allocated with hipMalloc and grown on demand.
+struct Workspace {
+    float4 *A = nullptr, *B = nullptr, *C = nullptr, *hit = nullptr;
+    uint32_t *q0 = nullptr, *q1 = nullptr;
+    uint32_t* counts = nullptr;         // 1024 words: per-bounce queue sizes, then the trace kernels' fetch cursors
+    Counters* counters = nullptr;
+    float* accum = nullptr;
+    uint64_t paths = 0, pixels = 0;     // capacity
+};
+
 struct rt_scene {
     int device = 0;
     DevScene dev{};
@@ -780,47 +808,55 @@ struct rt_scene {
     uint64_t deviceBytes = 0;
     uint32_t nodeCount = 0, leafTriCount = 0, depth = 0, modelCount = 0;
     int cuCount = 256;
-    // render workspace, grown on demand
-    uint64_t wsPaths = 0, wsPixels = 0;
-    void* wsA = nullptr; void* wsB = nullptr; void* wsC = nullptr; void* wsHit = nullptr;
-    void* wsQ0 = nullptr; void* wsQ1 = nullptr; void* wsCounts = nullptr; void* wsAccum = nullptr;
-    void* wsCounters = nullptr;
+    Workspace ws;                       // grown on demand by rt_render_device
     void* wsOut = nullptr; uint64_t wsOutPixels = 0;
-    std::vector<std::pair<const void*, int>> occupancy;   // resident blocks per CU of each persistent kernel
+    // Grid caps (resident blocks) of the persistent kernels, indexed [flag][spill]; filled at creation so
+    // that no later call has to query or allocate.
+    int gridTrace[2][2] = {{0, 0}, {0, 0}};
+    int gridIntersect[2][2] = {{0, 0}, {0, 0}};
+    // Events of RT_FLAG_PROFILE_KERNELS, kept for reuse across calls.
+    std::vector<hipEvent_t> eventPool;
+    // All device work of a handle shares one workspace; a call on another stream first waits for the
+    // stream of the previous call.
+    hipStream_t lastStream = nullptr;
+    bool hasLastStream = false;
 };
 
 namespace {
 
 void freeWorkspace(rt_scene* s) {
-    for (void** p : {&s->wsA, &s->wsB, &s->wsC, &s->wsHit, &s->wsQ0, &s->wsQ1, &s->wsAccum}) {
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-    }
-    s->wsPaths = 0;
-    s->wsPixels = 0;
+    Workspace& W = s->ws;
+    for (void* p : {static_cast<void*>(W.A), static_cast<void*>(W.B), static_cast<void*>(W.C), static_cast<void*>(W.hit),
+                    static_cast<void*>(W.q0), static_cast<void*>(W.q1), static_cast<void*>(W.accum)})
+        if (p) (void)hipFree(p);
+    W.A = W.B = W.C = W.hit = nullptr;
+    W.q0 = W.q1 = nullptr;
+    W.accum = nullptr;
+    W.paths = 0;
+    W.pixels = 0;
 }
 
-// Grid of a persistent kernel: every block must be resident at once (the static share of the line
-// stream assumes all waves run concurrently), so the cap is the kernel's own occupancy.
+// Resident blocks of a persistent kernel over the whole chip: every block must be resident at once (the
+// static share of the line stream assumes all waves run concurrently), so the cap is the kernel's own
+// occupancy.
 template <class Kernel>
-int persistentGrid(rt_scene* s, Kernel kernel, uint64_t items) {
-    const void* const key = reinterpret_cast<const void*>(kernel);
+int residentBlocks(const rt_scene* s, Kernel kernel) {
     int perCu = 0;
-    for (auto const& kv : s->occupancy) if (kv.first == key) perCu = kv.second;
-    if (perCu == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, RT_BLOCK, 0) != hipSuccess || perCu <= 0) perCu = 4;
-        if (std::getenv("RT_AMD_DEBUG")) std::fprintf(stderr, "rt_amd: persistent kernel %p: %d resident blocks per CU\n", key, perCu);
-        // Seven resident blocks (28 waves) per CU: measured best overall.  With eight, the 32 KB L1 of a
-        // CU is shared by more lines at once and its hit rate drops (-3 % on a 4 k-triangle scene, +0.4 %
-        // on a 0.9 M-triangle one); six or fewer lose latency hiding on the large scenes.
-        // RT_AMD_BLOCKS_PER_CU overrides the cap for tuning.
-        int cap = 7;
-        if (const char* text = std::getenv("RT_AMD_BLOCKS_PER_CU")) cap = std::max(1, std::atoi(text));
-        perCu = std::min(perCu, cap);
-        s->occupancy.emplace_back(key, perCu);
-    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, RT_BLOCK, 0) != hipSuccess || perCu <= 0) perCu = 4;
+    if (std::getenv("RT_AMD_DEBUG"))
+        std::fprintf(stderr, "rt_amd: persistent kernel %p: %d resident blocks per CU\n", reinterpret_cast<const void*>(kernel), perCu);
+    // Seven resident blocks (28 waves) per CU: measured best overall.  With eight, the 32 KB L1 of a
+    // CU is shared by more lines at once and its hit rate drops (-3 % on a 4 k-triangle scene, +0.4 %
+    // on a 0.9 M-triangle one); six or fewer lose latency hiding on the large scenes.
+    // RT_AMD_BLOCKS_PER_CU overrides the cap for tuning.
+    int cap = 7;
+    if (const char* text = std::getenv("RT_AMD_BLOCKS_PER_CU")) cap = std::max(1, std::atoi(text));
+    return s->cuCount * std::min(perCu, cap);
+}
+
+int persistentGrid(int residentCap, uint64_t items) {
     uint64_t const blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
-    return static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(blocks, static_cast<uint64_t>(s->cuCount) * perCu)));
+    return static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(blocks, static_cast<uint64_t>(residentCap))));
 }
 
 int gridFor(const rt_scene* s, uint64_t items) {
@@ -829,18 +865,33 @@ int gridFor(const rt_scene* s, uint64_t items) {
     return static_cast<int>(std::max<uint64_t>(1, std::min(blocks, cap)));
 }
 
+// Orders this call behind whatever the handle ran last on another stream.
+int adoptStream(rt_scene* s, hipStream_t st) {
+    if (s->hasLastStream && s->lastStream != st) HIP_TRY(hipStreamSynchronize(s->lastStream));
+    s->lastStream = st;
+    s->hasLastStream = true;
+    return RT_OK;
+}
+
+// No C++ exception may cross the C ABI: every entry point that can allocate runs its body through this.
+template <class Body>
+int guarded(const char* what, Body&& body) {
+    try { return body(); }
+    catch (std::bad_alloc const&) { return fail(RT_ERR_NOMEM, std::string(what) + ": out of host memory"); }
+    catch (std::exception const& e) { return fail(RT_ERR_INVALID, std::string(what) + ": " + e.what()); }
+    catch (...) { return fail(RT_ERR_INVALID, std::string(what) + ": unexpected exception"); }
+}
+
 }  // namespace
 
 // Error reporting for the other translation units of the library.
 int rt_internal_fail(int code, const char* message) { return fail(code, message ? message : ""); }
 
-extern "C" {
+namespace {
 
-const char* rt_last_error(void) { return g_lastError.c_str(); }
-uint32_t rt_abi_version(void) { return 3; }
-
-int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
+int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     if (!D || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
+    *out = nullptr;
     if (!D->model_pretri_begin || !D->model_vertex_begin || !D->leaf_first_ref)
         return fail(RT_ERR_INVALID, "rt_scene_create: null offset array in description");
     if ((D->model_count && (!D->model_tri_begin || !D->model_materials)) || (D->pretri_count && !D->pretris && !D->leaf_pretris)
@@ -957,7 +1008,8 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
         return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device available");
     if (device < 0 || device >= count) return fail(RT_ERR_INVALID, "rt_scene_create: device index out of range");
     HIP_TRY(hipSetDevice(device));
-    rt_scene* s = new rt_scene;
+    std::unique_ptr<rt_scene, void (*)(rt_scene*)> holder(new rt_scene, rt_scene_destroy);
+    rt_scene* s = holder.get();
     s->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -970,18 +1022,19 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     };
     size_t const matBytes = 48 * static_cast<size_t>(std::max<uint32_t>(D->model_count, 1));
     std::vector<float> mats(matBytes / 4, 0.0f);
-    std::memcpy(mats.data(), D->model_materials, 48 * static_cast<size_t>(D->model_count));
+    if (D->model_count) std::memcpy(mats.data(), D->model_materials, 48 * static_cast<size_t>(D->model_count));
+    void* dCounts = nullptr;
+    void* dCounters = nullptr;
     hipError_t e = upload(&s->dNodes, nodes.data(), nodes.size() * sizeof(HNode));
     if (e == hipSuccess) e = upload(&s->dLeafTris, leafTris.data(), leafTris.size() * 4);
     if (e == hipSuccess) e = upload(&s->dLeafIds, leafIds.data(), leafIds.size() * 4);
     if (e == hipSuccess) e = upload(&s->dTriNormals, triNormals.data(), triNormals.size() * 4);
     if (e == hipSuccess) e = upload(&s->dMaterials, mats.data(), matBytes);
-    if (e == hipSuccess) e = hipMalloc(&s->wsCounts, 4096);
-    if (e == hipSuccess) e = hipMalloc(&s->wsCounters, 1024);
-    if (e != hipSuccess) {
-        rt_scene_destroy(s);
-        return fail(RT_ERR_HIP, std::string("rt_scene_create: upload failed: ") + hipGetErrorString(e));
-    }
+    if (e == hipSuccess) e = hipMalloc(&dCounts, 4096);
+    s->ws.counts = static_cast<uint32_t*>(dCounts);
+    if (e == hipSuccess) e = hipMalloc(&dCounters, 1024);
+    s->ws.counters = static_cast<Counters*>(dCounters);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_scene_create: upload failed: ") + hipGetErrorString(e));
     s->dev.nodes = static_cast<const float4*>(s->dNodes);
     s->dev.leafTris = static_cast<const float4*>(s->dLeafTris);
     s->dev.leafIds = static_cast<const uint4*>(s->dLeafIds);
@@ -994,16 +1047,144 @@ int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     s->leafTriCount = refCount;
     s->depth = maxDepth;
     s->modelCount = D->model_count;
-    *out = s;
+    s->gridTrace[0][0] = residentBlocks(s, k_trace<false, false>);
+    s->gridTrace[0][1] = residentBlocks(s, k_trace<false, true>);
+    s->gridTrace[1][0] = residentBlocks(s, k_trace<true, false>);
+    s->gridTrace[1][1] = residentBlocks(s, k_trace<true, true>);
+    s->gridIntersect[0][0] = residentBlocks(s, k_intersect<false, false>);
+    s->gridIntersect[0][1] = residentBlocks(s, k_intersect<false, true>);
+    s->gridIntersect[1][0] = residentBlocks(s, k_intersect<true, false>);
+    s->gridIntersect[1][1] = residentBlocks(s, k_intersect<true, true>);
+    *out = holder.release();
     return RT_OK;
+}
+
+// The body of render(): batches of path slots through raygen, (trace, shade) per bounce and accumulate.
+// Uses only the buffers of W and calls nothing that allocates unless `profile` asks for new events.
+int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* stats, hipStream_t st, const Workspace& W,
+               uint32_t spb, bool profile) {
+    auto const t0 = std::chrono::steady_clock::now();
+    uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
+    uint32_t const bounceCount = p->bounce_limit + 1;      // intersections per path, src/render.hpp:88
+
+    PathState P;
+    P.A = W.A; P.B = W.B; P.C = W.C; P.hit = W.hit;
+    P.queue[0] = W.q0; P.queue[1] = W.q1;
+    P.counts = W.counts;
+    Counters* gc = W.counters;
+
+    RenderConst R;
+    std::memcpy(R.camPos, p->camera_position, 12);
+    std::memcpy(R.m, p->pixel_to_ray, 36);
+    R.width = p->width; R.x0 = p->x0; R.y0 = p->y0; R.w = p->w; R.h = p->h;
+    R.bounceLimit = p->bounce_limit; R.tMin = p->t_min;
+    R.key0 = static_cast<uint32_t>(p->seed); R.key1 = static_cast<uint32_t>(p->seed >> 32);
+    R.roulette = (p->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u;
+
+    bool const countWork = (p->flags & RT_FLAG_COUNT_WORK) != 0;
+    size_t eventsUsed = 0;
+    std::vector<int8_t> evKind;           // kind of the interval an event opens, -1 for a closing event
+    auto mark = [&](int kind) {
+        if (!profile) return;
+        if (eventsUsed == s->eventPool.size()) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) return;
+            s->eventPool.push_back(ev);
+        }
+        (void)hipEventRecord(s->eventPool[eventsUsed++], st);
+        evKind.push_back(static_cast<int8_t>(kind));
+    };
+
+    HIP_TRY(hipMemsetAsync(gc, 0, sizeof(Counters), st));
+    HIP_TRY(hipMemsetAsync(W.accum, 0, pixels * 12, st));
+    uint32_t batches = 0, traceLaunches = 0;
+    bool const spill = s->depth > RT_LDS_STACK_DEPTH;
+    int const traceCap = s->gridTrace[countWork ? 1 : 0][spill ? 1 : 0];
+    for (uint32_t done = 0; done < p->spp; done += spb) {
+        uint32_t const nb = std::min(spb, p->spp - done);
+        uint32_t const paths = static_cast<uint32_t>(pixels * nb);
+        int const grid = gridFor(s, paths);
+        int const traceGrid = persistentGrid(traceCap, paths);
+        HIP_TRY(hipMemsetAsync(P.counts, 0, 4096, st));
+        mark(0);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, R, P, static_cast<uint32_t>(pixels), done, paths);
+        mark(-1);
+        for (uint32_t b = 0; b < bounceCount; ++b) {
+            mark(1);
+#define RT_LAUNCH_TRACE(COUNT, SPILL)                                                                         \
+    hipLaunchKernelGGL((k_trace<COUNT, SPILL>), dim3(traceGrid), dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc)
+            if (countWork) { if (spill) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
+            else { if (spill) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
+#undef RT_LAUNCH_TRACE
+            mark(-1);
+            mark(2);
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, R, P, b, done, static_cast<uint32_t>(pixels), gc);
+            mark(-1);
+            ++traceLaunches;
+        }
+        int const last = done + nb >= p->spp;
+        mark(3);
+        hipLaunchKernelGGL(k_accumulate, dim3(static_cast<unsigned>((pixels + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK),
+                           0, st, P, W.accum, static_cast<uint32_t>(pixels), nb, bounceCount, last,
+                           static_cast<float>(p->spp), d_out, gc);
+        mark(-1);
+        ++batches;
+    }
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        Counters hc;
+        HIP_TRY(hipMemcpyAsync(&hc, gc, sizeof hc, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memset(stats, 0, sizeof *stats);
+        stats->paths = hc.paths; stats->segments = hc.segments; stats->shaded_hits = hc.shadedHits;
+        stats->box_tests = hc.boxTests; stats->tris_tested = hc.trisTested; stats->leaf_visits = hc.leafVisits;
+        stats->inode_visits = hc.inodeVisits;
+        stats->box_exact_fallbacks = hc.boxFallbacks; stats->box_filter_errors = hc.boxFilterErrors;
+        stats->trace_launches = traceLaunches; stats->batches = batches;
+        if (profile) {
+            double acc[4] = {0, 0, 0, 0};
+            for (size_t i = 0; i + 1 < eventsUsed; i += 2) {
+                float ms = 0.0f;
+                if (evKind[i] >= 0 && hipEventElapsedTime(&ms, s->eventPool[i], s->eventPool[i + 1]) == hipSuccess) acc[evKind[i]] += ms;
+            }
+            stats->ms_raygen = acc[0]; stats->ms_trace = acc[1]; stats->ms_shade = acc[2]; stats->ms_accumulate = acc[3];
+        }
+        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+int checkRenderParams(const rt_scene* s, const rt_render_params* p, const float* d_out) {
+    if (!s || !p || !d_out) return fail(RT_ERR_INVALID, "rt_render: null argument");
+    if (p->w == 0 || p->h == 0 || p->spp == 0) return fail(RT_ERR_INVALID, "rt_render: empty rectangle or zero spp");
+    if (static_cast<uint64_t>(p->x0) + p->w > p->width || static_cast<uint64_t>(p->y0) + p->h > p->height)
+        return fail(RT_ERR_INVALID, "rt_render: rectangle outside the image");
+    if (static_cast<uint64_t>(p->width) * p->height > 0xFFFFFFFFull)
+        return fail(RT_ERR_LIMIT, "rt_render: more than 2^32 pixels");
+    if (p->bounce_limit > 500 || p->bounce_limit + 3 > RT_FETCH_BASE) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit above 500");
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_lastError.c_str(); }
+uint32_t rt_abi_version(void) { return 4; }
+
+int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
+    return guarded("rt_scene_create", [&] { return sceneCreate(D, device, out); });
 }
 
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    if (s->hasLastStream) (void)hipStreamSynchronize(s->lastStream);
     freeWorkspace(s);
-    for (void* p : {s->dNodes, s->dLeafTris, s->dLeafIds, s->dTriNormals, s->dMaterials, s->wsCounts, s->wsCounters, s->wsOut})
+    for (void* p : {s->dNodes, s->dLeafTris, s->dLeafIds, s->dTriNormals, s->dMaterials, static_cast<void*>(s->ws.counts),
+                    static_cast<void*>(s->ws.counters), s->wsOut})
         if (p) (void)hipFree(p);
+    for (hipEvent_t ev : s->eventPool) (void)hipEventDestroy(ev);
     delete s;
 }
 
@@ -1023,17 +1204,19 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t const st = static_cast<hipStream_t>(hip_stream);
+    int const rcs = adoptStream(s, st);
+    if (rcs != RT_OK) return rcs;
     // The kernel hands out lines through a 32-bit cursor: larger batches go in slices.
     uint64_t const slice = 0xF0000000ull;
+    bool const spill = s->depth > RT_LDS_STACK_DEPTH;
+    int const cap = s->gridIntersect[front_only ? 1 : 0][spill ? 1 : 0];
     for (uint64_t done = 0; done < n; done += slice) {
         uint32_t const m = static_cast<uint32_t>(std::min<uint64_t>(slice, n - done));
-        uint32_t* cursor = static_cast<uint32_t*>(s->wsCounters) + 64;     // behind the Counters block
+        uint32_t* cursor = reinterpret_cast<uint32_t*>(s->ws.counters) + 64;     // behind the Counters block
         HIP_TRY(hipMemsetAsync(cursor, 0, 4, st));
 #define RT_LAUNCH_INTERSECT(FRONT, SPILL)                                                                     \
-    hipLaunchKernelGGL((k_intersect<FRONT, SPILL>), dim3(persistentGrid(s, k_intersect<FRONT, SPILL>, m)),        \
-                       dim3(RT_BLOCK), 0, st, s->dev, d_origins + 3 * done, d_directions + 3 * done, m, t_min,    \
-                       d_out + done, cursor)
-        bool const spill = s->depth > RT_LDS_STACK_DEPTH;
+    hipLaunchKernelGGL((k_intersect<FRONT, SPILL>), dim3(persistentGrid(cap, m)), dim3(RT_BLOCK), 0, st, s->dev,  \
+                       d_origins + 3 * done, d_directions + 3 * done, m, t_min, d_out + done, cursor)
         if (front_only) { if (spill) RT_LAUNCH_INTERSECT(true, true); else RT_LAUNCH_INTERSECT(true, false); }
         else { if (spill) RT_LAUNCH_INTERSECT(false, true); else RT_LAUNCH_INTERSECT(false, false); }
 #undef RT_LAUNCH_INTERSECT
@@ -1069,123 +1252,35 @@ int rt_intersect(rt_scene* s, const float* origins, const float* directions, uin
 }
 
 int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* stats, void* hip_stream) {
-    if (!s || !p || !d_out) return fail(RT_ERR_INVALID, "rt_render: null argument");
-    if (p->w == 0 || p->h == 0 || p->spp == 0) return fail(RT_ERR_INVALID, "rt_render: empty rectangle or zero spp");
-    if (static_cast<uint64_t>(p->x0) + p->w > p->width || static_cast<uint64_t>(p->y0) + p->h > p->height)
-        return fail(RT_ERR_INVALID, "rt_render: rectangle outside the image");
-    if (static_cast<uint64_t>(p->width) * p->height > 0xFFFFFFFFull)
-        return fail(RT_ERR_LIMIT, "rt_render: more than 2^32 pixels");
-    if (p->bounce_limit > 500) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit above 500");
-    HIP_TRY(hipSetDevice(s->device));
-    hipStream_t const st = static_cast<hipStream_t>(hip_stream);
-    auto const t0 = std::chrono::steady_clock::now();
-
-    uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
-    uint64_t const maxPaths = p->max_batch_paths ? p->max_batch_paths : (16ull << 20);
-    uint32_t const spb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(p->spp, maxPaths / pixels)));
-    uint64_t const batchPaths = pixels * spb;
-    if (batchPaths > 0xFFFFFFF0ull) return fail(RT_ERR_LIMIT, "rt_render: rectangle too large for one batch");
-
-    if (s->wsPaths < batchPaths || s->wsPixels < pixels) {
-        HIP_TRY(hipStreamSynchronize(st));
-        freeWorkspace(s);
-        HIP_TRY(hipMalloc(&s->wsA, batchPaths * 16));
-        HIP_TRY(hipMalloc(&s->wsB, batchPaths * 16));
-        HIP_TRY(hipMalloc(&s->wsC, batchPaths * 16));
-        HIP_TRY(hipMalloc(&s->wsHit, batchPaths * 16));
-        HIP_TRY(hipMalloc(&s->wsQ0, batchPaths * 4));
-        HIP_TRY(hipMalloc(&s->wsQ1, batchPaths * 4));
-        HIP_TRY(hipMalloc(&s->wsAccum, pixels * 12));
-        s->wsPaths = batchPaths;
-        s->wsPixels = pixels;
-    }
-    uint32_t const bounceCount = p->bounce_limit + 1;      // intersections per path, src/render.hpp:88
-    if (bounceCount + 2 > RT_FETCH_BASE) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit too large");
-
-    PathState P;
-    P.A = static_cast<float4*>(s->wsA); P.B = static_cast<float4*>(s->wsB); P.C = static_cast<float4*>(s->wsC);
-    P.hit = static_cast<float4*>(s->wsHit);
-    P.queue[0] = static_cast<uint32_t*>(s->wsQ0); P.queue[1] = static_cast<uint32_t*>(s->wsQ1);
-    P.counts = static_cast<uint32_t*>(s->wsCounts);
-    Counters* gc = static_cast<Counters*>(s->wsCounters);
-
-    RenderConst R;
-    std::memcpy(R.camPos, p->camera_position, 12);
-    std::memcpy(R.m, p->pixel_to_ray, 36);
-    R.width = p->width; R.x0 = p->x0; R.y0 = p->y0; R.w = p->w; R.h = p->h;
-    R.bounceLimit = p->bounce_limit; R.tMin = p->t_min;
-    R.key0 = static_cast<uint32_t>(p->seed); R.key1 = static_cast<uint32_t>(p->seed >> 32);
-
-    bool const countWork = (p->flags & RT_FLAG_COUNT_WORK) != 0;
-    bool const profile = (p->flags & RT_FLAG_PROFILE_KERNELS) != 0;
-    std::vector<hipEvent_t> events;           // pairs; kind in evKind
-    std::vector<int> evKind;
-    auto mark = [&](int kind) {
-        if (!profile) return;
-        hipEvent_t ev;
-        if (hipEventCreate(&ev) != hipSuccess) return;
-        (void)hipEventRecord(ev, st);
-        events.push_back(ev);
-        evKind.push_back(kind);
-    };
-
-    HIP_TRY(hipMemsetAsync(gc, 0, sizeof(Counters), st));
-    HIP_TRY(hipMemsetAsync(s->wsAccum, 0, pixels * 12, st));
-    uint32_t batches = 0, traceLaunches = 0;
-    for (uint32_t done = 0; done < p->spp; done += spb) {
-        uint32_t const nb = std::min(spb, p->spp - done);
-        uint32_t const paths = static_cast<uint32_t>(pixels * nb);
-        int const grid = gridFor(s, paths);
-        HIP_TRY(hipMemsetAsync(P.counts, 0, 4096, st));
-        mark(0);
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, R, P, static_cast<uint32_t>(pixels), done, paths);
-        mark(-1);
-        for (uint32_t b = 0; b < bounceCount; ++b) {
-            mark(1);
-#define RT_LAUNCH_TRACE(COUNT, SPILL)                                                                         \
-    hipLaunchKernelGGL((k_trace<COUNT, SPILL>), dim3(persistentGrid(s, k_trace<COUNT, SPILL>, paths)),            \
-                       dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc)
-            bool const spill = s->depth > RT_LDS_STACK_DEPTH;
-            if (countWork) { if (spill) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
-            else { if (spill) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
-#undef RT_LAUNCH_TRACE
-            mark(-1);
-            mark(2);
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, R, P, b, done, static_cast<uint32_t>(pixels), gc);
-            mark(-1);
-            ++traceLaunches;
+    return guarded("rt_render_device", [&]() -> int {
+        int const rc = checkRenderParams(s, p, d_out);
+        if (rc != RT_OK) return rc;
+        HIP_TRY(hipSetDevice(s->device));
+        hipStream_t const st = static_cast<hipStream_t>(hip_stream);
+        int const rcs = adoptStream(s, st);
+        if (rcs != RT_OK) return rcs;
+        uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
+        uint64_t const maxPaths = p->max_batch_paths ? p->max_batch_paths : (16ull << 20);
+        uint32_t const spb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(p->spp, maxPaths / pixels)));
+        uint64_t const batchPaths = pixels * spb;
+        if (batchPaths > 0xFFFFFFF0ull) return fail(RT_ERR_LIMIT, "rt_render: rectangle too large for one batch");
+        Workspace& W = s->ws;
+        if (W.paths < batchPaths || W.pixels < pixels) {
+            HIP_TRY(hipStreamSynchronize(st));
+            freeWorkspace(s);
+            void* ptr = nullptr;
+            HIP_TRY(hipMalloc(&ptr, batchPaths * 16)); W.A = static_cast<float4*>(ptr);
+            HIP_TRY(hipMalloc(&ptr, batchPaths * 16)); W.B = static_cast<float4*>(ptr);
+            HIP_TRY(hipMalloc(&ptr, batchPaths * 16)); W.C = static_cast<float4*>(ptr);
+            HIP_TRY(hipMalloc(&ptr, batchPaths * 16)); W.hit = static_cast<float4*>(ptr);
+            HIP_TRY(hipMalloc(&ptr, batchPaths * 4)); W.q0 = static_cast<uint32_t*>(ptr);
+            HIP_TRY(hipMalloc(&ptr, batchPaths * 4)); W.q1 = static_cast<uint32_t*>(ptr);
+            HIP_TRY(hipMalloc(&ptr, pixels * 12)); W.accum = static_cast<float*>(ptr);
+            W.paths = batchPaths;
+            W.pixels = pixels;
         }
-        int const last = done + nb >= p->spp;
-        mark(3);
-        hipLaunchKernelGGL(k_accumulate, dim3(static_cast<unsigned>((pixels + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK),
-                           0, st, P, static_cast<float*>(s->wsAccum), static_cast<uint32_t>(pixels), nb, bounceCount, last,
-                           static_cast<float>(p->spp), d_out, gc);
-        mark(-1);
-        ++batches;
-    }
-    HIP_TRY(hipGetLastError());
-    if (stats) {
-        Counters hc;
-        HIP_TRY(hipMemcpyAsync(&hc, gc, sizeof hc, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        std::memset(stats, 0, sizeof *stats);
-        stats->paths = hc.paths; stats->segments = hc.segments; stats->shaded_hits = hc.shadedHits;
-        stats->box_tests = hc.boxTests; stats->tris_tested = hc.trisTested; stats->leaf_visits = hc.leafVisits;
-        stats->inode_visits = hc.inodeVisits;
-        stats->box_exact_fallbacks = hc.boxFallbacks; stats->box_filter_errors = hc.boxFilterErrors;
-        stats->trace_launches = traceLaunches; stats->batches = batches;
-        if (profile) {
-            double acc[4] = {0, 0, 0, 0};
-            for (size_t i = 0; i + 1 < events.size(); i += 2) {
-                float ms = 0.0f;
-                if (hipEventElapsedTime(&ms, events[i], events[i + 1]) == hipSuccess && evKind[i] >= 0) acc[evKind[i]] += ms;
-            }
-            stats->ms_raygen = acc[0]; stats->ms_trace = acc[1]; stats->ms_shade = acc[2]; stats->ms_accumulate = acc[3];
-        }
-        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    }
-    for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
-    return RT_OK;
+        return renderCore(s, p, d_out, stats, st, W, spb, (p->flags & RT_FLAG_PROFILE_KERNELS) != 0);
+    });
 }
 
 int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* stats) {
@@ -1193,6 +1288,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* 
     HIP_TRY(hipSetDevice(s->device));
     uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
     if (s->wsOutPixels < pixels) {
+        if (s->hasLastStream) HIP_TRY(hipStreamSynchronize(s->lastStream));
         if (s->wsOut) (void)hipFree(s->wsOut);
         s->wsOut = nullptr;
         s->wsOutPixels = 0;
