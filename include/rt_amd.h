@@ -147,6 +147,19 @@ int rt_render(rt_scene* scene, const rt_render_params* params, float* out_rgb, r
 int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_out_rgb, rt_stats* stats,
                      void* hip_stream);
 
+/* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and same image, bit
+ * for bit, but the path state lives in a fixed array inside the library's code object (about 21 MiB per
+ * GPU, held until the process ends) instead of buffers grown with hipMalloc, and the call allocates
+ * nothing.  Limits: the rectangle holds at most RT_STATIC_MAX_PIXELS pixels (RT_ERR_LIMIT beyond that);
+ * each batch traces at most that many paths, so large sample counts take more, smaller batches;
+ * RT_FLAG_PROFILE_KERNELS is rejected.  With stats == NULL the call only enqueues work on hip_stream.
+ * Every call on one GPU, from any scene handle, shares that GPU's array: calls that overlap on one GPU
+ * race, so run them on one stream or separate them by a synchronisation. */
+#define RT_STATIC_MAX_PIXELS 262144u
+int rt_render_device_static(rt_scene* scene, const rt_render_params* params, float* d_out_rgb, rt_stats* stats,
+                            void* hip_stream);
+
 /* The steps between render() and the image file (src/main.cpp:233-240): reinhardToneMap, linearToSRGB,
  * nanToRed, infToGreen (src/image.hpp:15-70), medianFilter<1> (:73-109) and floatTo8BitUInt (:48-50).
  * hdr: width*height*3 floats as written by rt_render; rgb8: width*height*3 bytes, the payload of the

@@ -787,7 +787,9 @@ __global__ void k_selftest(int op, const float* __restrict__ a, const float* __r
 // Host side of the C ABI
 // ------------------------------------------------------------------------------------------------
 
-// Path-state buffers of one render call, allocated with hipMalloc and grown on demand.
+// Path-state buffers of one render call.  Two sets exist: the scene's own, allocated with hipMalloc and
+// grown on demand (rt_render_device), and a fixed-size one carved out of the file-scope `scratch`
+// array (rt_render_device_static), which never allocates.
 struct Workspace {
     float4 *A = nullptr, *B = nullptr, *C = nullptr, *hit = nullptr;
     uint32_t *q0 = nullptr, *q1 = nullptr;
@@ -809,6 +811,7 @@ struct rt_scene {
     uint32_t nodeCount = 0, leafTriCount = 0, depth = 0, modelCount = 0;
     int cuCount = 256;
     Workspace ws;                       // grown on demand by rt_render_device
+    Workspace wsStatic;                 // views into this GPU's copy of `scratch`
     void* wsOut = nullptr; uint64_t wsOutPixels = 0;
     // Grid caps (resident blocks) of the persistent kernels, indexed [flag][spill]; filled at creation so
     // that no later call has to query or allocate.
@@ -822,7 +825,49 @@ struct rt_scene {
     bool hasLastStream = false;
 };
 
+// ---- allocation-free workspace -------------------------------------------------------------------
+// rt_render_device_static keeps its whole path state in this array: no hipMalloc, hipFree or any other
+// allocating call on its path.  Layout (bytes): queue sizes and fetch cursors 4096 | counters 4096 |
+// A, B, C, hit 16*P each | two queues 4*P each | accumulator 12*P, with P = RT_STATIC_MAX_PATHS path
+// slots (and at most P pixels per call).  Every GPU holds its own copy at its own address; the host-side
+// name is only a handle for hipGetSymbolAddress, never a device address.
+#define RT_STATIC_MAX_PATHS (1u << 18)
+#define RT_STATIC_BYTES (8192ull + 84ull * RT_STATIC_MAX_PATHS)
+#define RT_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_BYTES];
+
 namespace {
+
+std::mutex g_scratchMutex;
+void* g_scratchPtr[RT_MAX_DEVICES] = {};      // device address of `scratch` on each GPU, resolved once per device
+
+// Resolves this GPU's address of `scratch` (the device must be current) and carves the workspace out of it.
+int bindStaticWorkspace(rt_scene* s) {
+    if (s->device < 0 || s->device >= RT_MAX_DEVICES) return RT_OK;      // rt_render_device_static reports it
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (!g_scratchPtr[s->device]) {
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(RT_ERR_HIP, "rt_scene_create: hipGetSymbolAddress returned a null address");
+        g_scratchPtr[s->device] = ptr;
+    }
+    unsigned char* base = static_cast<unsigned char*>(g_scratchPtr[s->device]);
+    size_t const P = RT_STATIC_MAX_PATHS;
+    Workspace& W = s->wsStatic;
+    W.counts = reinterpret_cast<uint32_t*>(base);
+    W.counters = reinterpret_cast<Counters*>(base + 4096);
+    unsigned char* q = base + 8192;
+    W.A = reinterpret_cast<float4*>(q); q += 16 * P;
+    W.B = reinterpret_cast<float4*>(q); q += 16 * P;
+    W.C = reinterpret_cast<float4*>(q); q += 16 * P;
+    W.hit = reinterpret_cast<float4*>(q); q += 16 * P;
+    W.q0 = reinterpret_cast<uint32_t*>(q); q += 4 * P;
+    W.q1 = reinterpret_cast<uint32_t*>(q); q += 4 * P;
+    W.accum = reinterpret_cast<float*>(q);
+    W.paths = P;
+    W.pixels = P;
+    return RT_OK;
+}
 
 void freeWorkspace(rt_scene* s) {
     Workspace& W = s->ws;
@@ -1055,6 +1100,8 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     s->gridIntersect[0][1] = residentBlocks(s, k_intersect<false, true>);
     s->gridIntersect[1][0] = residentBlocks(s, k_intersect<true, false>);
     s->gridIntersect[1][1] = residentBlocks(s, k_intersect<true, true>);
+    int const rc = bindStaticWorkspace(s);
+    if (rc != RT_OK) return rc;
     *out = holder.release();
     return RT_OK;
 }
@@ -1281,6 +1328,25 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
         }
         return renderCore(s, p, d_out, stats, st, W, spb, (p->flags & RT_FLAG_PROFILE_KERNELS) != 0);
     });
+}
+
+int rt_render_device_static(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* stats, void* hip_stream) {
+    int const rc = checkRenderParams(s, p, d_out);
+    if (rc != RT_OK) return rc;
+    uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
+    if (pixels > RT_STATIC_MAX_PATHS)
+        return fail(RT_ERR_LIMIT, "rt_render_device_static: rectangle larger than 262144 pixels (RT_STATIC_MAX_PIXELS)");
+    if (p->flags & RT_FLAG_PROFILE_KERNELS)
+        return fail(RT_ERR_INVALID, "rt_render_device_static: RT_FLAG_PROFILE_KERNELS creates events and is not available here");
+    if (!s->wsStatic.A) return fail(RT_ERR_LIMIT, "rt_render_device_static: no static workspace on this device index");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t const st = static_cast<hipStream_t>(hip_stream);
+    int const rcs = adoptStream(s, st);
+    if (rcs != RT_OK) return rcs;
+    uint64_t maxPaths = RT_STATIC_MAX_PATHS;
+    if (p->max_batch_paths) maxPaths = std::min<uint64_t>(maxPaths, std::max<uint64_t>(p->max_batch_paths, pixels));
+    uint32_t const spb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(p->spp, maxPaths / pixels)));
+    return renderCore(s, p, d_out, stats, st, s->wsStatic, spb, false);
 }
 
 int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* stats) {

@@ -126,6 +126,15 @@ class DeviceScene:
                                                ctypes.c_void_p(stream or 0)))
         return st.as_dict() if want_stats else None
 
+    def render_device_static(self, params, d_out, stream=None, want_stats=True):
+        """rt_render_device_static: the same image from the library's fixed workspace, no allocation."""
+        st = _lib.RtStats()
+        dp = ctypes.c_void_p(d_out.data_ptr() if hasattr(d_out, "data_ptr") else int(d_out))
+        _lib.check(_lib.lib().rt_render_device_static(self._h, ctypes.byref(params), dp,
+                                                      ctypes.byref(st) if want_stats else None,
+                                                      ctypes.c_void_p(stream or 0)))
+        return st.as_dict() if want_stats else None
+
 
 class RenderData:
     """src/render.hpp:38-44."""
