@@ -49,7 +49,7 @@ int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------------
 // Node record, 32 bytes = two float4:  q0 = {lo.x, lo.y, lo.z, hi.x}  q1 = {hi.y, hi.z, index, aux}
 //   index > 0 : interior; children are nodes[index] (negative side) and nodes[index+1] (positive);
-//               aux = division axis.  The split plane is the centre of the node's own box on that
+//               aux = division axis (bits 0-1), negative child empty (bit 2), positive child empty (bit 3).  The split plane is the centre of the node's own box on that
 //               axis, which is how BSPTree computes positiveChild.box.min[axis] (src/bsp.hpp:256-274).
 //   index < 0 : leaf; triangles are leafTris[-index-1 .. -index-1+aux)
 //   index == 0: empty
@@ -321,18 +321,33 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             }
             if (meets && index > 0) {
                 if (COUNT) c.inodeVisits++;
-                float const la = aux == 0 ? nlo.x : (aux == 1 ? nlo.y : nlo.z);
-                float const ha = aux == 0 ? nhi.x : (aux == 1 ? nhi.y : nhi.z);
-                float const oa = aux == 0 ? o.x : (aux == 1 ? o.y : o.z);
+                uint32_t const axis = aux & 3u;
+                float const la = axis == 0 ? nlo.x : (axis == 1 ? nlo.y : nlo.z);
+                float const ha = axis == 0 ? nhi.x : (axis == 1 ? nhi.y : nhi.z);
+                float const oa = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
                 float const plane = (la + ha) / 2.0f;
                 bool const positiveNear = (oa - plane) >= 0.0f;            // src/bsp.hpp:133
                 uint32_t const base = static_cast<uint32_t>(index);
                 uint32_t const farChild = positiveNear ? base : base + 1;
-                if (!SPILL || sp < RT_LDS_STACK_DEPTH) stack[sp * RT_BLOCK] = farChild;
-                else spillStack[sp - RT_LDS_STACK_DEPTH] = farChild;
-                ++sp;
-                cur = positiveNear ? base + 1 : base;                       // near child
-                continue;
+                uint32_t const nearChild = positiveNear ? base + 1 : base;
+                // Visiting an empty child has no effect whatever its box test says (src/bsp.hpp:106-117 returns
+                // nullopt for index 0), so the kernels that do not count work never go there: bits 2 and 3 of
+                // aux say which children are empty.
+                bool const nearEmpty = !COUNT && (aux & (positiveNear ? 8u : 4u)) != 0u;
+                bool const farEmpty = !COUNT && (aux & (positiveNear ? 4u : 8u)) != 0u;
+                if (nearEmpty) {
+                    if (!farEmpty) { cur = farChild; continue; }
+                }
+                else {
+                    if (!farEmpty) {
+                        if (!SPILL || sp < RT_LDS_STACK_DEPTH) stack[sp * RT_BLOCK] = farChild;
+                        else spillStack[sp - RT_LDS_STACK_DEPTH] = farChild;
+                        ++sp;
+                    }
+                    cur = nearChild;
+                    continue;
+                }
+                // both children empty: fall through to the pop below with nothing found here
             }
             uint32_t const here = cur;
             if (sp > 0) {                                                   // what follows this node
@@ -999,7 +1014,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
                 return fail(RT_ERR_INVALID, "rt_scene_create: tree is not split at box centres");
             uint32_t const pair = static_cast<uint32_t>(nodes.size());
             nodes[it.nodeSlot].index = static_cast<int32_t>(pair);
-            nodes[it.nodeSlot].aux = in.axis;
+            nodes[it.nodeSlot].aux = in.axis | (in.neg_index == 0 ? 4u : 0u) | (in.pos_index == 0 ? 8u : 0u);
             HNode a{}, b{};
             std::memcpy(a.lo, in.neg_box, 12); std::memcpy(a.hi, in.neg_box + 3, 12);
             std::memcpy(b.lo, in.pos_box, 12); std::memcpy(b.hi, in.pos_box + 3, 12);
