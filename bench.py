@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the render hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cornell|builtin|dragon]
+    python bench.py --gpus N --steps K --warmup W [--workload dragon|cornell|builtin|dragon4k|multi]
+                    [--scaling weak|strong] [--spp S] [--no-cpu-baseline]
 
 One step = one render() of the workload frame: camera rays, BSP traversal, ray/triangle tests, GGX
 shading and per-pixel accumulation for every sample of every pixel, with the scene already resident
 in HBM and the image written to HBM (no PCIe in the timed region).  Metric: Mrays/s = path segments
 (closest-hit queries issued by the path loop, src/render.hpp:104) per second, whole job.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is cut into horizontal bands
-dealt round-robin to the ranks and gathered to rank 0 with one RCCL all-gather per frame, inside the
-timed region.  Scaling is weak: the sample count per pixel is 64*N, so every GPU traces the same number
-of paths as the single-GPU run.
+Default workload: the ~0.9 M-triangle scene at 1920x1080, 256 samples per pixel, 8 bounces.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): rank 0 prepares the scene and broadcasts it
+once as a byte buffer; the frame is cut into horizontal bands dealt round-robin to the ranks and gathered
+to rank 0 (RCCL) once per frame, inside the timed region.  --scaling weak (default): the sample count per
+pixel is spp*N, so every GPU traces as many paths as the single-GPU run; --scaling strong: the frame's
+sample count is fixed and the ranks share it (e.g. dragon4k: 3840x2160 at 1024 spp over 2/4/8 GPUs).
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,20 +30,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
-FP32_VALU_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E
+FP32_VALU_PEAK_TFLOPS = 157.3              # = 2 flop x 64 lanes x VALU_PEAK_WAVE_INSTR_PER_S
+VALU_PEAK_WAVE_INSTR_PER_S = 157.3e12 / 128.0
 
 WORKLOADS = {
-    # name: (scene factory, width, height, spp per GPU, bounce limit, description)
-    "cornell": ("cornell_scene", 1920, 1080, 64, 8,
-                "Cornell-box-style room, ~4k triangles, mixed GGX roughness, 1920x1080, 64 spp, 8 bounces"),
-    "builtin": ("builtin_scene", 640, 480, 16, 8,
-                "reference built-in scene (src/main.cpp:134-187), 640x480, 16 spp, 8 bounces"),
-    "dragon": ("dragon_scale_scene", 1920, 1080, 256, 8,
+    # name: (scene factory, width, height, spp per GPU (weak), spp of the frame (strong), bounce limit, description)
+    "dragon": ("dragon_scale_scene", 1920, 1080, 256, 256, 8,
                "displaced closed surface, ~0.9M triangles (dragon-scale stand-in), 1920x1080, 256 spp, 8 bounces"),
-    "dragon4k": ("dragon_scale_scene", 3840, 2160, 128, 8,
-                 "displaced closed surface, ~0.9M triangles, 3840x2160, 128 spp per GPU (1024 spp on 8 GPUs), 8 bounces"),
-    "multi": ("multi_mesh_scene", 1920, 1080, 64, 12,
+    "cornell": ("cornell_scene", 1920, 1080, 64, 64, 8,
+                "Cornell-box-style room, ~4k triangles, mixed GGX roughness, 1920x1080, 64 spp, 8 bounces"),
+    "builtin": ("builtin_scene", 640, 480, 16, 16, 8,
+                "reference built-in scene (src/main.cpp:134-187), 640x480, 16 spp, 8 bounces"),
+    "dragon4k": ("dragon_scale_scene", 3840, 2160, 128, 1024, 8,
+                 "displaced closed surface, ~0.9M triangles, 3840x2160, 1024 spp per frame (128 per GPU when weak), 8 bounces"),
+    "multi": ("multi_mesh_scene", 1920, 1080, 64, 64, 12,
               "eleven instances of the 0.9M-triangle surface (~9.9M triangles), GGX roughness 0.04-0.1, 1920x1080, "
               "64 spp, 12 bounces"),
 }
@@ -51,10 +56,22 @@ def build_scene(name):
     return factory().preprocess()
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(scene, width, height, bounce_limit, target_seconds=12.0):
-    """The oracle's CPU restatement of the same path (same scene, resolution, bounce limit, sampler),
-    threaded over pixels, on a bounded sample: full frame at 1 spp to calibrate, then as many spp as fit
-    in about target_seconds."""
+    """The reference's algorithm and parallel decomposition on the host: the oracle's restatement of the same
+    path with the 8-triangle AVX2/FMA leaf test (src/geometry.hpp:117-132), threads over pixels
+    (src/render.hpp:218) on this process's share of the host cores, same scene, resolution, bounce limit and
+    sampler, on a bounded sample: full frame at 1 spp to calibrate, then as many spp as fit in about
+    target_seconds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import binding
     from helpers import base_from_scene
@@ -63,6 +80,7 @@ def cpu_baseline(scene, width, height, bounce_limit, target_seconds=12.0):
     # which is O(nodes x triangles) and would take hours on the large workloads).
     osc = binding.oracle().scene_create_with_tree(base_from_scene(scene), width, height, scene.bsp_tree)
     try:
+        osc.set_simd_leaves(True)
         t0 = time.perf_counter()
         _, st = osc.render_device_mode(osc.render_params(1, bounce_limit=bounce_limit), threads=threads)
         t1 = time.perf_counter() - t0
@@ -72,9 +90,86 @@ def cpu_baseline(scene, width, height, bounce_limit, target_seconds=12.0):
         dt = time.perf_counter() - t0
     finally:
         osc.close()
-    out = {"value": st["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-           "sample": f"full {width}x{height} frame at {spp} spp ({st['segments']} segments in {dt:.2f} s)",
-           "segments_per_path": st["segments"] / st["paths"]}
+    return {"value": st["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port-avx2",
+            "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "sample": f"full {width}x{height} frame at {spp} spp ({st['segments']} segments in {dt:.2f} s), "
+                      f"8-triangle AVX2+FMA leaf test, {threads} threads over pixels",
+            "segments_per_path": st["segments"] / st["paths"]}
+
+
+def roofline(workload, work, seg_per_launch, launch_ms, trace_share):
+    """Ceilings for k_trace, the dominant kernel.  Live inputs: segments per launch and the average launch
+    duration (HIP events around every k_trace launch of the timed steps) and the work counters of an untimed
+    counting step.  Counter inputs: per-segment HBM bytes, VALU instructions and cache accesses of k_trace from
+    the committed rocprofv3 --pmc passes of this workload (profiles/roofline_<workload>.json, made by
+    tools/roofline_passes.sh; a PMC pass cannot run inside the timed region), and the ceilings measured by the
+    calibration kernels of tools/ubench/peaks.hip in the same passes."""
+    seg_per_s = seg_per_launch / (launch_ms * 1e-3) if launch_ms > 0 else 0.0
+    bpt = (28.0 * work["box_tests"] + 52.0 * work["tris_tested"]) / work["segments"]
+    fps = (30.0 * work["box_tests"] + 38.0 * work["tris_tested"]) / work["segments"]
+    ceilings = {
+        "algorithmic_zero_reuse": {
+            "note": "28 B per node box test + 52 B per triangle tested, every byte counted as if it came from HBM; "
+                    "informational only: these bytes are served by L1/L2, so this is not a bound",
+            "bytes_per_segment": bpt, "gbytes_per_s": bpt * seg_per_s / 1e9, "flops_per_segment": fps,
+            "tflops": fps * seg_per_s / 1e12, "frac_of_fp32_valu_peak": fps * seg_per_s / 1e12 / FP32_VALU_PEAK_TFLOPS},
+    }
+    out = {"kernel": "k_trace", "avg_launch_ms": launch_ms, "segments_per_launch": seg_per_launch,
+           "segments_per_s_in_kernel": seg_per_s, "trace_share_of_kernel_time": trace_share,
+           "box_tests_per_segment": work["box_tests"] / work["segments"],
+           "tris_tested_per_segment": work["tris_tested"] / work["segments"],
+           "shaded_hits_per_segment": work["shaded_hits"] / work["segments"]}
+    pmc_file = os.path.join(ROOT, "profiles", f"roofline_{workload}.json")
+    traffic = None
+    if os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        d = pmc.get("k_trace_per_segment", {})
+        peaks = pmc.get("peaks_unprofiled", {})
+        out["counters_file"] = os.path.relpath(pmc_file, ROOT)
+        if "hbm_bytes_per_segment" in d:
+            traffic = d["hbm_bytes_per_segment"] * seg_per_launch
+            a = d["hbm_bytes_per_segment"] * seg_per_s / 1e9
+            ceilings["hbm"] = {"achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                               "bytes_per_segment": d["hbm_bytes_per_segment"],
+                               "note": "measured HBM bytes: (2*FETCH_SIZE + WRITE_SIZE) KiB of k_trace, separate --pmc passes"}
+        if "valu_wave_instr_per_segment" in d:
+            a = d["valu_wave_instr_per_segment"] * seg_per_s
+            lanes = d["active_lanes_per_valu_instr"] / 64.0
+            ceilings["valu"] = {"achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_PER_S / 1e9, "unit": "G wave-instructions/s",
+                                "frac": a / VALU_PEAK_WAVE_INSTR_PER_S, "active_lane_fraction": lanes,
+                                "lane_slot_frac": a / VALU_PEAK_WAVE_INSTR_PER_S * lanes,
+                                "measured_peak_fma_stream": peaks.get("valu_wave_instr_per_s", 0) / 1e9,
+                                "note": "SQ_INSTS_VALU per segment x segments/s against 2 wave64 instructions per cycle and CU "
+                                        "at 2.4 GHz (the 157.3 TFLOP/s FP32 vector peak); lanes = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU"}
+        if "l1_accesses_per_segment" in d and peaks.get("gather16_lane_loads_per_s_l1"):
+            a = d["l1_accesses_per_segment"] * seg_per_s
+            miss1, hit2 = d["l1_miss_rate"], d["l2_hit_rate"]
+            p1, p2, p3 = (peaks[f"gather16_lane_loads_per_s_{k}"] for k in ("l1", "l2", "mall"))
+            mix_peak = 1.0 / ((1.0 - miss1) / p1 + miss1 * hit2 / p2 + miss1 * (1.0 - hit2) / p3)
+            ceilings["texture_path"] = {
+                "achieved": a / 1e9, "peak": mix_peak / 1e9, "unit": "G lane-loads/s", "frac": a / mix_peak,
+                "peak_all_l1_hits": p1 / 1e9, "frac_of_all_l1_hits_peak": a / p1,
+                "l1_miss_rate": miss1, "l2_hit_rate": hit2,
+                "td_busy_vs_pure_gather_kernel": (d.get("td_busy_per_gui_cycle", 0.0) / pmc["peak_gather_td_busy_per_gui_cycle"])
+                if pmc.get("peak_gather_td_busy_per_gui_cycle") else None,
+                "ta_busy_vs_pure_gather_kernel": (d.get("ta_busy_per_gui_cycle", 0.0) / pmc["peak_gather_ta_busy_per_gui_cycle"])
+                if pmc.get("peak_gather_ta_busy_per_gui_cycle") else None,
+                "note": "TCP_TOTAL_CACHE_ACCESSES (one per lane of a scattered 16-byte load) x segments/s against the rate of "
+                        "tools/ubench/peaks.hip's scattered 16-byte loads served from L1 / L2 / Infinity Cache, weighted by this "
+                        "kernel's measured L1 miss and L2 hit rates"}
+    bound = max((k for k in ceilings if "frac" in ceilings[k]), key=lambda k: ceilings[k]["frac"], default=None)
+    if bound is None:
+        # no counter file for this workload: only the FP32 VALU fraction of the algorithmic flops can be stated
+        z = ceilings["algorithmic_zero_reuse"]
+        out.update({"bound": "valu", "achieved": z["tflops"], "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": z["frac_of_fp32_valu_peak"], "traffic": None})
+    else:
+        b = ceilings[bound]
+        out.update({"bound": {"hbm": "hbm", "valu": "valu", "texture_path": "texture-path"}[bound], "achieved": b["achieved"],
+                    "peak": b["peak"], "unit": b["unit"], "frac": b["frac"], "traffic": traffic,
+                    "traffic_note": "measured HBM bytes per k_trace launch (PMC), against "
+                                    f"{bpt * seg_per_launch:.3e} algorithmic zero-reuse bytes per launch"})
+    out["ceilings"] = ceilings
     return out
 
 
@@ -83,15 +178,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per GPU")
+    ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU when weak, per frame when strong)")
+    ap.add_argument("--roulette", action="store_true", help="render with RT_FLAG_RUSSIAN_ROULETTE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from raytracing_amd import _lib, tiles
-    from raytracing_amd.render import DeviceScene, RayTraceData
+    from raytracing_amd.render import DeviceScene, RayTraceData, serialize_scene
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -103,12 +200,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # Rehearsal on a box with fewer GPUs than ranks (RT_BENCH_SHARE_GPU=1): every rank renders on GPU 0 and
-    # the bands are gathered over gloo through host memory.  The numbers of such a run mean nothing; it
+    # scene bytes and bands travel over gloo through host memory.  The numbers of such a run mean nothing; it
     # exists to exercise the multi-rank code path.
     share_gpu = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    comm_device = "cpu" if share_gpu else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
@@ -116,45 +214,72 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    _, width, height, spp1, bounce_limit, description = WORKLOADS[args.workload]
-    spp1 = args.spp or spp1
-    spp = spp1 * world                      # weak scaling: constant paths per GPU
-    scene = build_scene(args.workload)
-    ds = DeviceScene(RayTraceData(scene), device=local_rank)
-    p2r = scene.pixel_to_ray_transform(width, height)
-    stream = torch.cuda.current_stream().cuda_stream
-    bands_per_rank = 8          # tools/band_balance.py: max/mean rank load 1.03 at 8 ranks on the 0.9M-triangle scene (1.07 with 4)
-    buf = torch.zeros(tiles.max_rank_rows(height, world, bands_per_rank) * width * 3, dtype=torch.float32, device="cuda")
+    _, width, height, spp_weak, spp_strong, bounce_limit, description = WORKLOADS[args.workload]
+    if args.scaling == "weak":
+        spp1 = args.spp or spp_weak
+        spp = spp1 * world                  # constant paths per GPU
+    else:
+        spp = args.spp or spp_strong        # fixed frame; each GPU traces 1/world of it
+        spp1 = spp / world
 
-    def step(seed, flags):
+    # ---- scene: prepared once on rank 0, broadcast as bytes, uploaded by every rank ---------------------------
+    t_setup = time.perf_counter()
+    scene = None
+    if rank == 0:
+        scene = build_scene(args.workload)
+        rtd = RayTraceData(scene)
+        header = np.concatenate([scene.camera.position, scene.pixel_to_ray_transform(width, height),
+                                 [len(scene.preprocessed_tris.tris)]]).astype(np.float64)
+    if world > 1:
+        blob = tiles.broadcast_bytes(serialize_scene(rtd) if rank == 0 else None, rank, dist, comm_device)
+        head = torch.from_numpy(header).to(comm_device) if rank == 0 else torch.zeros(13, dtype=torch.float64, device=comm_device)
+        dist.broadcast(head, src=0)
+        header = head.cpu().numpy()
+        ds = DeviceScene(rtd, device=local_rank) if rank == 0 else DeviceScene.from_blob(blob, device=local_rank)
+        scene_bytes = int(blob.size)
+        del blob
+    else:
+        ds = DeviceScene(rtd, device=local_rank)
+        scene_bytes = 0
+    cam_pos, p2r, triangles = header[0:3].astype(np.float32), header[3:12].astype(np.float32), int(header[12])
+    setup_s = time.perf_counter() - t_setup
+
+    stream = torch.cuda.current_stream().cuda_stream
+    # One rectangle per GPU when alone; 8 bands per rank otherwise (tools/band_balance.py: max/mean rank load
+    # 1.03 at 8 ranks on the 0.9M-triangle scene, 1.07 with 4).
+    bands_per_rank = 1 if world == 1 else 8
+    render_buf = torch.zeros(tiles.max_rank_rows(height, world, bands_per_rank) * width * 3, dtype=torch.float32, device="cuda")
+    gatherer = tiles.FrameGatherer(width, height, rank, world, bands_per_rank, dist,
+                                   buffer=(torch.zeros(render_buf.numel()) if share_gpu and world > 1 else render_buf))
+    extra = _lib.RT_FLAG_RUSSIAN_ROULETTE if args.roulette else 0
+
+    def step(seed, flags, spp_step):
         def render_rect(x0, y0, w, h, out):
-            p = ds.make_params(width, height, scene.camera.position, p2r, spp=spp, bounce_limit=bounce_limit,
-                               seed=seed, rect=(x0, y0, w, h), flags=flags)
+            p = ds.make_params(width, height, cam_pos, p2r, spp=spp_step, bounce_limit=bounce_limit,
+                               seed=seed, rect=(x0, y0, w, h), flags=flags | extra)
             return ds.render_device(p, out, stream=stream)
-        st = tiles.render_sharded(render_rect, width, height, rank, world, buf, bands_per_rank)
+        st = tiles.render_sharded(render_rect, width, height, rank, world, render_buf, bands_per_rank)
         if share_gpu and world > 1:
             torch.cuda.synchronize()
-            frame = tiles.gather_frame(buf.cpu(), width, height, rank, world, bands_per_rank, dist)
-        else:
-            frame = tiles.gather_frame(buf, width, height, rank, world, bands_per_rank, dist)
-        return st, frame
+            gatherer.buffer.copy_(render_buf.cpu())
+        return st, gatherer.gather()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed: algorithmic work per segment for the roofline (box tests B, triangles tested T, shaded hits H).
-    work, _ = step(1000, _lib.RT_FLAG_COUNT_WORK) if rank == 0 or world > 1 else ({}, None)
+    # Untimed: work per segment for the roofline (box tests, triangles tested, shaded hits), on one batch.
+    work, _ = step(1000, _lib.RT_FLAG_COUNT_WORK, min(spp, 8))
     for i in range(args.warmup):
-        step(i, 0)
+        step(i, 0, spp)
     fence()
     t0 = time.perf_counter()
     seg = 0
     trace_ms = shade_ms = 0.0
     launches = 0
     for i in range(args.steps):
-        st, frame = step(100 + i, _lib.RT_FLAG_PROFILE_KERNELS)
+        st, frame = step(100 + i, _lib.RT_FLAG_PROFILE_KERNELS, spp)
         seg += st["segments"]
         trace_ms += st["ms_trace"]
         shade_ms += st["ms_shade"]
@@ -162,49 +287,29 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    seg_rank = seg
     if world > 1:
-        t = torch.tensor([dt, float(seg)], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        t = torch.tensor([dt, float(seg)], dtype=torch.float64, device=comm_device)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, seg = float(tmax[0]), float(t[1])
     if rank == 0:
         finite = bool(torch.isfinite(frame).all())
-        # Algorithmic bytes of the traversal kernel: 28 B per node box test (box + index) and 52 B per
-        # triangle tested (48 B preprocessed triangle + 4 B id); shading adds 84 B per shaded hit.
-        bpt = (28.0 * work["box_tests"] + 52.0 * work["tris_tested"]) / work["segments"]
-        fps = (30.0 * work["box_tests"] + 38.0 * work["tris_tested"]) / work["segments"]
-        seg_rank0 = seg / world
-        trace_s = trace_ms / 1e3
-        achieved = bpt * seg_rank0 / trace_s / 1e9 if trace_s > 0 else 0.0
-        traffic = None
-        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(traffic_file) and args.workload == "cornell" and world == 1 and not args.spp:
-            # HBM bytes per k_trace launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-            # this same command (a PMC pass cannot run inside the timed region).
-            traffic = json.load(open(traffic_file)).get("k_trace", {}).get("hbm_bytes_per_launch")
         line = {
             "metric": "Mrays/s (path segments/s) at 1080p" if height == 1080 else "Mrays/s (path segments/s)",
             "value": seg / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (procedural scene, random-free geometry; counter-based sampler)",
             "config": {"workload": description, "name": args.workload, "width": width, "height": height,
                        "spp_total": spp, "spp_per_gpu": spp1, "bounce_limit": bounce_limit,
-                       "triangles": int(len(scene.preprocessed_tris.tris)), "tree_depth": ds.depth,
-                       "parallelism": f"pixel bands over {world} GPU(s), scene replicated, 1 all-gather per frame",
-                       "segments_per_step": seg / args.steps, "image_finite": finite},
-            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/hbm_traffic.json; "
-                                         "the algorithmic bytes are served by L1/L2, so achieved exceeds what HBM moves",
-                         "algorithmic_bytes_per_segment": bpt, "segments_per_launch": seg_rank0 / max(launches, 1),
-                         "avg_launch_ms": trace_ms / max(launches, 1),
-                         "box_tests_per_segment": work["box_tests"] / work["segments"],
-                         "tris_tested_per_segment": work["tris_tested"] / work["segments"],
-                         "shaded_hits_per_segment": work["shaded_hits"] / work["segments"],
-                         "valu_tflops": fps * seg_rank0 / trace_s / 1e12 if trace_s > 0 else 0.0,
-                         "valu_frac": (fps * seg_rank0 / trace_s / 1e12 / FP32_VALU_PEAK_TFLOPS) if trace_s > 0 else 0.0,
-                         "trace_share_of_kernel_time": trace_ms / max(trace_ms + shade_ms, 1e-9)},
+                       "russian_roulette": bool(args.roulette), "triangles": triangles, "tree_depth": ds.depth,
+                       "parallelism": (f"pixel bands over {world} GPUs, scene broadcast once from rank 0 "
+                                       f"({scene_bytes / 1e6:.1f} MB), bands gathered to rank 0 every frame") if world > 1
+                       else "one GPU, one rectangle",
+                       "scene_setup_s": setup_s, "segments_per_step": seg / args.steps, "image_finite": finite},
+            "roofline": roofline(args.workload, work, seg_rank / max(launches, 1), trace_ms / max(launches, 1),
+                                 trace_ms / max(trace_ms + shade_ms, 1e-9)),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, width, height, bounce_limit)

@@ -130,6 +130,15 @@ typedef struct {
 /* Upload a scene to GPU `device` (replaces constructing RayTraceData, src/main.cpp:219-229). */
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
+/* A scene description as one contiguous, position-independent byte buffer, for handing a prepared scene to
+ * other processes (one process per GPU: rank 0 prepares the scene and broadcasts the buffer once; the
+ * reference is a single process and has no counterpart).  rt_scene_serialize with blob == NULL stores the
+ * size needed in *size; otherwise *size is the capacity on entry and the bytes written on return.
+ * rt_scene_desc_from_blob points a description at the arrays inside the buffer (no copy; the buffer must be
+ * 8-byte aligned and outlive the description); rt_scene_create_from_blob uploads straight from it. */
+int rt_scene_serialize(const rt_scene_desc* desc, void* blob, uint64_t* size);
+int rt_scene_desc_from_blob(const void* blob, uint64_t size, rt_scene_desc* out_desc);
+int rt_scene_create_from_blob(const void* blob, uint64_t size, int device, rt_scene** out);
 /* Bytes of HBM held by the scene, and the depth of its tree. */
 int rt_scene_info(const rt_scene* scene, uint64_t* device_bytes, uint32_t* node_count, uint32_t* leaf_tri_count,
                   uint32_t* depth);

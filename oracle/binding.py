@@ -35,7 +35,10 @@ class RenderParams(ctypes.Structure):
     _fields_ = [("width", _c.c_uint32), ("height", _c.c_uint32), ("x0", _c.c_uint32), ("y0", _c.c_uint32),
                 ("w", _c.c_uint32), ("h", _c.c_uint32), ("spp", _c.c_uint32), ("bounceLimit", _c.c_uint32),
                 ("tMin", _c.c_float), ("seed", _c.c_uint64), ("cameraPosition", _c.c_float * 3),
-                ("pixelToRay", _c.c_float * 9)]
+                ("pixelToRay", _c.c_float * 9), ("flags", _c.c_uint32)]
+
+
+FLAG_RUSSIAN_ROULETTE = 4
 
 
 class Stats(ctypes.Structure):
@@ -161,7 +164,7 @@ class _Lib:
               _c.c_int32(t.root_index), _p(inodes), _c.c_uint32(t.inode_count), _p(first), _p(refs),
               _c.c_uint32(t.leaf_count))
         if not h:
-            raise RuntimeError("scene_create_with_tree failed (a leaf holds more than 32 triangles)")
+            raise RuntimeError("scene_create_with_tree failed")
         return Scene(self, h, width, height)
 
     def scene_builtin(self, divisor, width, height):
@@ -254,9 +257,15 @@ class Scene:
         return img
 
     # -- device-mode (C oracle only) ----------------------------------------------------------
-    def render_params(self, spp, seed=0x5EED, bounce_limit=8, t_min=1e-3, rect=None):
-        pre = self.preprocessed()
+    def set_simd_leaves(self, enable=True):
+        """C oracle only: leaf test 8 triangles per AVX2 step (src/geometry.hpp:117-132) instead of one at a time."""
+        self.L.lib.orc_scene_set_simd_leaves(self.h, _c.c_int(int(enable)))
+
+    def render_params(self, spp, seed=0x5EED, bounce_limit=8, t_min=1e-3, rect=None, flags=0):
+        pre = dict(camera_position=np.zeros(3, np.float32), pixel_to_ray=np.zeros(9, np.float32))
+        self.L.lib.orc_get_camera(self.h, _p(pre["camera_position"]), _p(pre["pixel_to_ray"]))
         p = RenderParams()
+        p.flags = flags
         p.width, p.height = self.width, self.height
         x0, y0, w, h = rect if rect is not None else (0, 0, self.width, self.height)
         p.x0, p.y0, p.w, p.h = x0, y0, w, h

@@ -3,6 +3,7 @@
  * All `file:line` citations are relative to /root/reference. */
 #include "rt_oracle.h"
 
+#include <immintrin.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -204,7 +205,13 @@ void orc_fast_rng_floats(uint64_t seed, size_t n, float* out) {
 
 typedef struct { box3 box; int32_t index; } bsp_node;                  /* src/bsp.hpp:148-153 */
 typedef struct { bsp_node neg, pos; uint8_t axis; } bsp_inode;         /* src/bsp.hpp:155-159 */
-typedef struct { uint32_t mesh[32], tri[32]; pretri tris[32]; uint8_t count; } bsp_leaf; /* src/bsp.hpp:161-168 */
+/* Leaf, src/bsp.hpp:161-168: the reference holds up to 32 triangles in four 8-wide blocks.  Here a leaf is a
+ * range of the scene-wide reference arrays (refMesh/refTri/refTris), so that trees with larger leaves (which
+ * only the product's depth-capped builder can make) can be traversed with the same scan; `firstBlock` indexes
+ * the 8-wide structure-of-arrays copies used by the AVX2 leaf test. */
+typedef struct { uint32_t first, count, firstBlock; } bsp_leaf;
+/* PreprocessedTriBlock, src/geometry.hpp:53-58: normal, v1, v1ToV3, v1ToV2 of 8 triangles, one array per component. */
+typedef struct { float c[12][8]; } tri_block;
 
 struct orc_scene {
     uint32_t modelCount, vertexCount, triCount, baseVertexCount, baseTriCount, meshCount, materialCount;
@@ -223,6 +230,9 @@ struct orc_scene {
     bsp_node root;
     bsp_inode* inodes; uint32_t inodeCount, inodeCap;
     bsp_leaf* leaves; uint32_t leafCount, leafCap;
+    uint32_t* refMesh; uint32_t* refTri; pretri* refTris; uint32_t refCount, refCap;
+    tri_block* blocks; uint32_t blockCount;
+    int simdLeaves;                /* leaf test: 0 = one triangle at a time, 1 = AVX2, 8 triangles per step */
     int buildFailed;
 };
 
@@ -289,7 +299,7 @@ static void inverse_transpose3(const v3 m[3], v3 out[3]) {
 static bsp_node create_node(orc_scene* s, box3 box, int axis, int depth) {
     bsp_node node; node.box = box; node.index = 0;
     if (depth > 64) { s->buildFailed = 1; return node; }
-    bsp_leaf leaf; leaf.count = 0;
+    struct { uint32_t mesh[32], tri[32]; pretri tris[32]; uint32_t count; } leaf; leaf.count = 0;
     int subdivide = 0;
     for (uint32_t inst = 0; inst < s->modelCount && !subdivide; ++inst) {
         const uint32_t* mtr = s->meshTriRanges + 2 * s->modelMeshes[inst];
@@ -314,7 +324,19 @@ static bsp_node create_node(orc_scene* s, box3 box, int axis, int depth) {
             s->leafCap = s->leafCap ? 2 * s->leafCap : 64;
             s->leaves = (bsp_leaf*)realloc(s->leaves, s->leafCap * sizeof(bsp_leaf));
         }
-        s->leaves[s->leafCount++] = leaf;
+        if (s->refCount + leaf.count > s->refCap) {
+            s->refCap = s->refCap ? 2 * s->refCap : 1024;
+            s->refMesh = (uint32_t*)realloc(s->refMesh, s->refCap * sizeof(uint32_t));
+            s->refTri = (uint32_t*)realloc(s->refTri, s->refCap * sizeof(uint32_t));
+            s->refTris = (pretri*)realloc(s->refTris, s->refCap * sizeof(pretri));
+        }
+        bsp_leaf rec = {s->refCount, leaf.count, 0};
+        for (uint32_t k = 0; k < leaf.count; ++k) {
+            s->refMesh[s->refCount] = leaf.mesh[k]; s->refTri[s->refCount] = leaf.tri[k];
+            s->refTris[s->refCount] = leaf.tris[k];
+            ++s->refCount;
+        }
+        s->leaves[s->leafCount++] = rec;
         node.index = -(int32_t)s->leafCount;                           /* :249 */
         return node;
     }
@@ -443,6 +465,23 @@ static orc_scene* scene_prepare(const float* positions, const float* normals, ui
     return s;
 }
 
+/* The 8-wide copies of every leaf's triangles (Leaf::tris, src/bsp.hpp:165; unused lanes are zero). */
+static void build_blocks(orc_scene* s) {
+    uint32_t total = 0;
+    for (uint32_t l = 0; l < s->leafCount; ++l) { s->leaves[l].firstBlock = total; total += (s->leaves[l].count + 7) / 8; }
+    s->blocks = (tri_block*)aligned_alloc(32, sizeof(tri_block) * (size_t)(total ? total : 1));
+    memset(s->blocks, 0, sizeof(tri_block) * (size_t)(total ? total : 1));
+    s->blockCount = total;
+    for (uint32_t l = 0; l < s->leafCount; ++l)
+        for (uint32_t k = 0; k < s->leaves[l].count; ++k) {
+            const float* src = (const float*)&s->refTris[s->leaves[l].first + k];
+            tri_block* b = &s->blocks[s->leaves[l].firstBlock + k / 8];
+            for (int c = 0; c < 12; ++c) b->c[c][k % 8] = src[c];
+        }
+}
+
+void orc_scene_set_simd_leaves(orc_scene* s, int enable) { s->simdLeaves = enable ? 1 : 0; }
+
 orc_scene* orc_scene_create(const float* positions, const float* normals, uint32_t vertexCount,
                             const uint32_t* tris, uint32_t triCount,
                             const uint32_t* meshVertexRanges, const uint32_t* meshTriRanges, uint32_t meshCount,
@@ -455,6 +494,7 @@ orc_scene* orc_scene_create(const float* positions, const float* normals, uint32
                                  modelCount, camera, width, height, inflateMode);
     s->root = create_node(s, s->rootBox, 0, 0);
     if (s->buildFailed) { orc_scene_destroy(s); return NULL; }
+    build_blocks(s);
     return s;
 }
 
@@ -482,16 +522,23 @@ orc_scene* orc_scene_create_with_tree(const float* positions, const float* norma
     }
     s->leaves = (bsp_leaf*)calloc(leafCount ? leafCount : 1, sizeof(bsp_leaf));
     s->leafCount = s->leafCap = leafCount;
+    uint32_t refs = leafFirstRef[leafCount];
+    s->refCount = s->refCap = refs;
+    s->refMesh = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(refs ? refs : 1));
+    s->refTri = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(refs ? refs : 1));
+    s->refTris = (pretri*)malloc(sizeof(pretri) * (size_t)(refs ? refs : 1));
     for (uint32_t l = 0; l < leafCount; ++l) {
-        uint32_t n = leafFirstRef[l + 1] - leafFirstRef[l];
-        if (n > 32) { orc_scene_destroy(s); return NULL; }              /* Leaf::MAX_TRIS, src/bsp.hpp:162 */
-        s->leaves[l].count = (uint8_t)n;
-        for (uint32_t k = 0; k < n; ++k) {
-            uint32_t mesh = leafRefs[2 * (size_t)(leafFirstRef[l] + k)], tri = leafRefs[2 * (size_t)(leafFirstRef[l] + k) + 1];
-            s->leaves[l].mesh[k] = mesh; s->leaves[l].tri[k] = tri;
-            s->leaves[l].tris[k] = s->pretris[s->triRanges[2 * mesh] + tri];
-        }
+        /* Leaves above Leaf::MAX_TRIS (src/bsp.hpp:162) cannot exist in the reference; the scan below
+         * extends to them unchanged (ascending order, strict <). */
+        s->leaves[l].first = leafFirstRef[l];
+        s->leaves[l].count = leafFirstRef[l + 1] - leafFirstRef[l];
     }
+    for (uint32_t r = 0; r < refs; ++r) {
+        uint32_t mesh = leafRefs[2 * (size_t)r], tri = leafRefs[2 * (size_t)r + 1];
+        s->refMesh[r] = mesh; s->refTri[r] = tri;
+        s->refTris[r] = s->pretris[s->triRanges[2 * mesh] + tri];
+    }
+    build_blocks(s);
     return s;
 }
 
@@ -499,7 +546,7 @@ void orc_scene_destroy(orc_scene* s) {
     if (!s) return;
     free(s->baseTris); free(s->meshTriRanges); free(s->modelMeshes); free(s->positions); free(s->normals);
     free(s->vertexRanges); free(s->pretris); free(s->triRanges); free(s->modelMaterials);
-    free(s->inodes); free(s->leaves); free(s);
+    free(s->inodes); free(s->leaves); free(s->refMesh); free(s->refTri); free(s->refTris); free(s->blocks); free(s);
 }
 
 void orc_scene_counts(const orc_scene* s, uint32_t* c) {
@@ -527,6 +574,11 @@ void orc_get_preprocessed(const orc_scene* s, float* positions, float* normals, 
     memcpy(rootBox, &s->rootBox, 24);
 }
 
+void orc_get_camera(const orc_scene* s, float* cameraPosition, float* pixelToRay) {
+    st3(cameraPosition, s->cameraPosition);
+    memcpy(pixelToRay, s->pixelToRay, 36);
+}
+
 void orc_get_bsp(const orc_scene* s, float* rootBox, int32_t* rootIndex, float* inodeBoxes, int32_t* inodeInts,
                  uint32_t* leafCounts, uint32_t* leafRefs) {
     memcpy(rootBox, &s->root.box, 24);
@@ -542,8 +594,8 @@ void orc_get_bsp(const orc_scene* s, float* rootBox, int32_t* rootIndex, float* 
         const bsp_leaf* l = &s->leaves[i];
         leafCounts[i] = l->count;
         for (uint32_t j = 0; j < 32; ++j) {
-            leafRefs[((size_t)i * 32 + j) * 2] = j < l->count ? l->mesh[j] : 0xFFFFFFFFu;
-            leafRefs[((size_t)i * 32 + j) * 2 + 1] = j < l->count ? l->tri[j] : 0xFFFFFFFFu;
+            leafRefs[((size_t)i * 32 + j) * 2] = j < l->count ? s->refMesh[l->first + j] : 0xFFFFFFFFu;
+            leafRefs[((size_t)i * 32 + j) * 2 + 1] = j < l->count ? s->refTri[l->first + j] : 0xFFFFFFFFu;
         }
     }
 }
@@ -571,14 +623,74 @@ static inline int line_tri(const pretri* p, v3 o, v3 d, int frontOnly, float* t,
     return detCheck && (*u >= 0.0f) && (*v >= 0.0f) && (*u + *v <= 1.0f);
 }
 
+/* lineTrisIntersection<Surfaces> for one block of 8 triangles, src/geometry.hpp:117-132, with the AVX2/FMA
+ * operations of src/utility/vectorised.hpp:405-481: dot = fmadd(z,z, fmadd(y,y, x*x)), cross component =
+ * fmsub(a.y,b.z, a.z*b.y), unary minus = 0 - x.  Lane k gets the bits line_tri() gives triangle k. */
+static inline __m256 dot8(__m256 ax, __m256 ay, __m256 az, __m256 bx, __m256 by, __m256 bz) {
+    return _mm256_fmadd_ps(az, bz, _mm256_fmadd_ps(ay, by, _mm256_mul_ps(ax, bx)));
+}
+static inline int line_tris8(const tri_block* b, v3 o, v3 d, int frontOnly, float* t, float* u, float* v) {
+    __m256 const nx = _mm256_load_ps(b->c[0]), ny = _mm256_load_ps(b->c[1]), nz = _mm256_load_ps(b->c[2]);
+    __m256 const dx = _mm256_set1_ps(d.x), dy = _mm256_set1_ps(d.y), dz = _mm256_set1_ps(d.z);
+    __m256 const negDet = dot8(nx, ny, nz, dx, dy, dz);
+    __m256 const invDet = _mm256_div_ps(_mm256_set1_ps(-1.0f), negDet);
+    __m256 const aox = _mm256_sub_ps(_mm256_set1_ps(o.x), _mm256_load_ps(b->c[3]));
+    __m256 const aoy = _mm256_sub_ps(_mm256_set1_ps(o.y), _mm256_load_ps(b->c[4]));
+    __m256 const aoz = _mm256_sub_ps(_mm256_set1_ps(o.z), _mm256_load_ps(b->c[5]));
+    __m256 const tt = _mm256_mul_ps(dot8(aox, aoy, aoz, nx, ny, nz), invDet);
+    __m256 const cx = _mm256_fmsub_ps(aoy, dz, _mm256_mul_ps(aoz, dy));
+    __m256 const cy = _mm256_fmsub_ps(aoz, dx, _mm256_mul_ps(aox, dz));
+    __m256 const cz = _mm256_fmsub_ps(aox, dy, _mm256_mul_ps(aoy, dx));
+    __m256 const uu = _mm256_mul_ps(dot8(_mm256_load_ps(b->c[6]), _mm256_load_ps(b->c[7]), _mm256_load_ps(b->c[8]), cx, cy, cz), invDet);
+    __m256 const vv = _mm256_mul_ps(_mm256_sub_ps(_mm256_setzero_ps(),
+                                                  dot8(_mm256_load_ps(b->c[9]), _mm256_load_ps(b->c[10]), _mm256_load_ps(b->c[11]), cx, cy, cz)),
+                                    invDet);
+    __m256 const zero = _mm256_setzero_ps();
+    __m256 det;
+    if (frontOnly) det = _mm256_cmp_ps(negDet, _mm256_set1_ps(-1e-6f), _CMP_LE_OQ);
+    else det = _mm256_cmp_ps(_mm256_andnot_ps(_mm256_set1_ps(-0.0f), negDet), _mm256_set1_ps(1e-6f), _CMP_GE_OQ);
+    __m256 const ok = _mm256_and_ps(_mm256_and_ps(det, _mm256_cmp_ps(uu, zero, _CMP_GE_OQ)),
+                                    _mm256_and_ps(_mm256_cmp_ps(vv, zero, _CMP_GE_OQ),
+                                                  _mm256_cmp_ps(_mm256_add_ps(uu, vv), _mm256_set1_ps(1.0f), _CMP_LE_OQ)));
+    _mm256_storeu_ps(t, tt); _mm256_storeu_ps(u, uu); _mm256_storeu_ps(v, vv);
+    return _mm256_movemask_ps(ok);
+}
+
 /* src/bsp.hpp:58-104 */
 static int visit_leaf(const traverser* tr, const box3* box, const bsp_leaf* leaf, hit_rec* out) {
     hit_rec best; best.t = INFINITY;
     int has = 0;
+    const orc_scene* s = tr->s;
     if (tr->st) { tr->st->leafVisits++; tr->st->trisTested += leaf->count; }
+    if (s->simdLeaves) {
+        /* :61-69 blocks of 8, then :73-97 the ascending scan over the stored results */
+        for (uint32_t base = 0; base < leaf->count; base += 8) {
+            float t8[8], u8[8], v8[8];
+            int mask = line_tris8(&s->blocks[leaf->firstBlock + base / 8], tr->o, tr->d, tr->frontOnly, t8, u8, v8);
+            uint32_t n = leaf->count - base < 8 ? leaf->count - base : 8;
+            mask &= (1 << n) - 1;
+            while (mask) {
+                int k = __builtin_ctz((unsigned)mask);
+                mask &= mask - 1;
+                float t = t8[k];
+                if (t < best.t && t >= tr->tMin) {
+                    v3 p = V(tr->o.x + t * tr->d.x, tr->o.y + t * tr->d.y, tr->o.z + t * tr->d.z);
+                    int inBox = p.x >= box->min.x && p.x <= box->max.x && p.y >= box->min.y && p.y <= box->max.y
+                             && p.z >= box->min.z && p.z <= box->max.z;
+                    if (inBox) {
+                        best.t = t; best.u = u8[k]; best.v = v8[k]; best.point = p;
+                        best.mesh = s->refMesh[leaf->first + base + (uint32_t)k]; best.tri = s->refTri[leaf->first + base + (uint32_t)k];
+                        has = 1;
+                    }
+                }
+            }
+        }
+        if (has) *out = best;
+        return has;
+    }
     for (uint32_t i = 0; i < leaf->count; ++i) {
         float t, u, v;
-        if (line_tri(&leaf->tris[i], tr->o, tr->d, tr->frontOnly, &t, &u, &v)) {
+        if (line_tri(&s->refTris[leaf->first + i], tr->o, tr->d, tr->frontOnly, &t, &u, &v)) {
             if (t < best.t && t >= tr->tMin) {
                 /* Line::operator(), src/geometry.hpp:30-32: separate multiply and add. */
                 v3 p = V(tr->o.x + t * tr->d.x, tr->o.y + t * tr->d.y, tr->o.z + t * tr->d.z);
@@ -586,7 +698,7 @@ static int visit_leaf(const traverser* tr, const box3* box, const bsp_leaf* leaf
                          && p.z >= box->min.z && p.z <= box->max.z;
                 if (inBox) {
                     best.t = t; best.u = u; best.v = v; best.point = p;
-                    best.mesh = leaf->mesh[i]; best.tri = leaf->tri[i];
+                    best.mesh = s->refMesh[leaf->first + i]; best.tri = s->refTri[leaf->first + i];
                     has = 1;
                 }
             }
@@ -752,19 +864,20 @@ void orc_sincos_2pi(float u, float* s, float* c) {
 }
 
 /* Two uniform numbers for dimension pair `dim` (0 = pixel jitter, b+1 = bounce b). */
-static inline void sampler_pair(sampler* sm, uint32_t dim, float* u0, float* u1raw) {
-    if (!sm->deviceMode) { *u0 = rng_unit(sm->rng); *u1raw = rng_unit(sm->rng); return; }
+static inline void sampler_pair(sampler* sm, uint32_t dim, float* u0, float* u1raw, float* u2) {
+    if (!sm->deviceMode) { *u0 = rng_unit(sm->rng); *u1raw = rng_unit(sm->rng); *u2 = 0.0f; return; }
     uint32_t ctr[4] = {sm->pixel, sm->sample, dim, 0u}, out[4];
     orc_philox4x32_10(ctr, sm->key, out);
     *u0 = orc_u32_to_unit_float(out[0]);
     *u1raw = orc_u32_to_unit_float(out[1]);
+    *u2 = orc_u32_to_unit_float(out[2]);     /* third word of the same block: Russian roulette */
 }
 
 /* src/render.hpp:53-212.  The reference stores per-bounce terms in 8 AVX lanes and evaluates them
  * after the loop; the per-lane arithmetic is independent, so evaluating bounce b's weight when it is
  * produced and keeping a running throughput gives the same bits:
  *   lightWeights[k] = w[k-1] * lightWeights[k-1], outgoing = fma(lightWeights[k], emission[k], outgoing). */
-static v3 ray_trace(const orc_scene* s, v3 o, v3 d, sampler* sm, uint32_t bounceLimit, float tMin, orc_stats* st) {
+static v3 ray_trace(const orc_scene* s, v3 o, v3 d, sampler* sm, uint32_t bounceLimit, float tMin, int roulette, orc_stats* st) {
     v3 throughput = V(1.0f, 1.0f, 1.0f), light = V(0.0f, 0.0f, 0.0f);
     uint32_t bounce = 0;
     for (;;) {
@@ -782,8 +895,8 @@ static v3 ray_trace(const orc_scene* s, v3 o, v3 d, sampler* sm, uint32_t bounce
         if (nDotO < 0.0f) { nDotO = -nDotO; normal = neg3(normal); }
         v3 p1, p2;
         orthonormal_basis(normal, &p1, &p2);
-        float thetaParam, u1;
-        sampler_pair(sm, bounce + 1, &thetaParam, &u1);
+        float thetaParam, u1, u2;
+        sampler_pair(sm, bounce + 1, &thetaParam, &u1, &u2);
         float cosThetaSq = 1.0f / (1.0f + m->ndfAlphaSq * thetaParam / (1.0f - thetaParam));
         float cosTheta = sqrtf(cosThetaSq);
         float sinTheta = sqrtf(1.0f - cosThetaSq);
@@ -798,6 +911,17 @@ static v3 ray_trace(const orc_scene* s, v3 o, v3 d, sampler* sm, uint32_t bounce
         if (!(nDotI > 0.0f)) break;                                            /* :169-175 */
         v3 w = bounce_weight(m, nDotO, nDotI, cosTheta, hDotO);
         throughput = V(w.x * throughput.x, w.y * throughput.y, w.z * throughput.z);
+        /* Russian roulette (device mode only; the reference has none, its paths end at the bounce limit,
+         * src/render.hpp:117): from the third bounce on, survive with probability min(1, largest throughput
+         * component) and divide the throughput by it. */
+        if (roulette && bounce >= 2u) {
+            float big = throughput.x;
+            if (throughput.y > big) big = throughput.y;
+            if (throughput.z > big) big = throughput.z;
+            float survive = big < 1.0f ? big : 1.0f;
+            if (u2 >= survive) break;
+            throughput = V(throughput.x / survive, throughput.y / survive, throughput.z / survive);
+        }
         o = h.point; d = incident;
         ++bounce;
     }
@@ -809,7 +933,7 @@ void orc_ray_trace(const orc_scene* s, const float* origins, const float* direct
     for (size_t i = 0; i < n; ++i) {
         fast_rng r = {seeds[i]};
         sampler sm; memset(&sm, 0, sizeof sm); sm.rng = &r;
-        st3(out + 3 * i, ray_trace(s, ld3(origins + 3 * i), ld3(directions + 3 * i), &sm, 8, 1e-3f, NULL));
+        st3(out + 3 * i, ray_trace(s, ld3(origins + 3 * i), ld3(directions + 3 * i), &sm, 8, 1e-3f, 0, NULL));
     }
 }
 
@@ -825,7 +949,7 @@ void orc_render(const orc_scene* s, uint32_t spp, uint64_t seed, float* image) {
             float sx = (float)px + rng_unit(&r);
             float sy = (float)py + rng_unit(&r);
             v3 d = camera_ray(s->pixelToRay, sx, sy);
-            colour = add3(colour, ray_trace(s, s->cameraPosition, d, &sm, 8, 1e-3f, NULL));
+            colour = add3(colour, ray_trace(s, s->cameraPosition, d, &sm, 8, 1e-3f, 0, NULL));
         }
         float n = (float)spp;
         st3(image + 3 * index, V(colour.x / n, colour.y / n, colour.z / n));
@@ -838,12 +962,12 @@ void orc_path_radiance_device_mode(const orc_scene* s, const orc_render_params* 
     sm.deviceMode = 1;
     sm.key[0] = (uint32_t)p->seed; sm.key[1] = (uint32_t)(p->seed >> 32);
     sm.pixel = pixelY * p->width + pixelX; sm.sample = sample;
-    float jx, jy;
-    sampler_pair(&sm, 0, &jx, &jy);
+    float jx, jy, unused;
+    sampler_pair(&sm, 0, &jx, &jy, &unused);
     float sx = (float)pixelX + jx, sy = (float)pixelY + jy;
     v3 d = camera_ray(p->pixelToRay, sx, sy);
     if (st) st->paths++;
-    st3(rgb, ray_trace(s, ld3(p->cameraPosition), d, &sm, p->bounceLimit, p->tMin, st));
+    st3(rgb, ray_trace(s, ld3(p->cameraPosition), d, &sm, p->bounceLimit, p->tMin, (p->flags & ORC_FLAG_RUSSIAN_ROULETTE) != 0, st));
 }
 
 void orc_render_device_mode(const orc_scene* s, const orc_render_params* p, float* image, orc_stats* stats, int threads) {

@@ -56,7 +56,8 @@ orc_scene* orc_scene_create(const float* positions, const float* normals, uint32
                             int inflateMode);
 /* Same preprocessing, but with a tree supplied by the caller (interior nodes in the 60-byte layout of
  * BSPTree::INode, src/bsp.hpp:148-159; leaf triangle references as {model, tri} pairs): lets the oracle
- * traverse trees far too large for the reference's O(nodes x triangles) build.  NULL if a leaf exceeds 32. */
+ * traverse trees far too large for the reference's O(nodes x triangles) build, and trees with leaves above
+ * Leaf::MAX_TRIS made by the product's depth-capped builder. */
 orc_scene* orc_scene_create_with_tree(const float* positions, const float* normals, uint32_t vertexCount,
                                       const uint32_t* tris, uint32_t triCount,
                                       const uint32_t* meshVertexRanges, const uint32_t* meshTriRanges, uint32_t meshCount,
@@ -67,6 +68,10 @@ orc_scene* orc_scene_create_with_tree(const float* positions, const float* norma
                                       int32_t rootIndex, const void* inodes60, uint32_t inodeCount,
                                       const uint32_t* leafFirstRef, const uint32_t* leafRefs, uint32_t leafCount);
 void orc_scene_destroy(orc_scene*);
+/* Leaf test: 0 (default) one triangle at a time; 1 the reference's own shape, 8 triangles per AVX2/FMA step
+ * (src/geometry.hpp:117-132).  Same bits either way; the second is what the CPU baseline times. */
+void orc_scene_set_simd_leaves(orc_scene*, int enable);
+void orc_get_camera(const orc_scene*, float* cameraPosition, float* pixelToRay);
 
 /* counts: [0] models [1] instantiated vertices [2] preprocessed tris [3] inodes [4] leaves
  *         [5] base vertices [6] base tris [7] base meshes [8] materials */
@@ -103,7 +108,11 @@ typedef struct {
     uint64_t seed;
     float cameraPosition[3];
     float pixelToRay[9];             /* column-major, src/camera.hpp:45 */
+    uint32_t flags;                  /* ORC_FLAG_* */
 } orc_render_params;
+/* Russian roulette from the third bounce on (an estimator extension of the product, not in the reference):
+ * survive with probability min(1, largest throughput component), throughput divided by it. */
+#define ORC_FLAG_RUSSIAN_ROULETTE 4u
 
 typedef struct {
     uint64_t segments;               /* closest-hit queries issued by the path loop (src/render.hpp:104) */

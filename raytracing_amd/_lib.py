@@ -65,7 +65,7 @@ RT_FLAG_RUSSIAN_ROULETTE = 4
 RT_STATIC_MAX_PIXELS = 262144
 
 # Every symbol declared by include/rt_amd.h and include/rt_host.h.
-DEVICE_SYMBOLS = ["rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_intersect", "rt_intersect_device",
+DEVICE_SYMBOLS = ["rt_scene_create", "rt_scene_serialize", "rt_scene_desc_from_blob", "rt_scene_create_from_blob", "rt_scene_destroy", "rt_scene_info", "rt_intersect", "rt_intersect_device",
                   "rt_render", "rt_render_device", "rt_render_device_static", "rt_postprocess", "rt_postprocess_device", "rt_selftest_math",
                   "rt_last_error", "rt_abi_version"]
 HOST_SYMBOLS = ["rt_preprocess_material", "rt_quat_from_euler", "rt_camera_basis", "rt_pixel_to_ray_transform",

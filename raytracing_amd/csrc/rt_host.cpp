@@ -9,12 +9,16 @@
 #include <atomic>
 #include <thread>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
 #include <vector>
+
+// Sets the calling thread's error message (rt_last_error) and returns `code`; defined beside the device code.
+int rt_internal_fail(int code, const char* message);
 
 namespace {
 
@@ -448,9 +452,9 @@ int rt_bsp_build(const float* inst_positions, const uint32_t* model_vertex_begin
                  const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,
                  const float root_box[6], uint32_t max_leaf_tris, uint32_t max_depth, int threads, rt_bsp** out) {
     if (!inst_positions || !model_vertex_begin || !base_tris || !mesh_tri_ranges || !model_meshes || !root_box || !out
-        || max_leaf_tris == 0) return RT_ERR_INVALID;
+        || max_leaf_tris == 0) return rt_internal_fail(RT_ERR_INVALID, "rt_bsp_build: null argument or max_leaf_tris == 0");
     rt_bsp* bsp = new (std::nothrow) rt_bsp;
-    if (!bsp) return RT_ERR_NOMEM;
+    if (!bsp) return rt_internal_fail(RT_ERR_NOMEM, "rt_bsp_build: out of host memory");
     try {
         std::vector<TriGeom> tris;
         size_t total = 0;
@@ -541,7 +545,11 @@ int rt_bsp_build(const float* inst_positions, const uint32_t* model_vertex_begin
     }
     catch (std::bad_alloc const&) {
         delete bsp;
-        return RT_ERR_NOMEM;
+        return rt_internal_fail(RT_ERR_NOMEM, "rt_bsp_build: out of host memory");
+    }
+    catch (...) {
+        delete bsp;
+        return rt_internal_fail(RT_ERR_INVALID, "rt_bsp_build: unexpected exception");
     }
     *out = bsp;
     return RT_OK;
@@ -564,6 +572,126 @@ void rt_bsp_view(const rt_bsp* bsp, float root_box[6], int32_t* root_index, cons
     *inodes = bsp->inodes.data();
     *leaf_first_ref = bsp->leaf_first.data();
     *leaf_refs = bsp->refs.data();
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Scene description <-> one contiguous byte buffer (for shipping a prepared scene to other processes)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct BlobHeader {
+    uint32_t magic, version;
+    float root_box[6];
+    int32_t root_index;
+    uint32_t inode_count, leaf_count, ref_count, pretri_count, vertex_count, base_tri_count, model_count;
+    uint32_t has_pretris, has_leaf_pretris;
+    uint64_t total_bytes;
+};
+constexpr uint32_t kBlobMagic = 0x42535452u;      // "RTSB"
+constexpr uint32_t kBlobVersion = 1;
+inline size_t pad16(size_t n) { return (n + 15) & ~static_cast<size_t>(15); }
+
+// The arrays of a description in blob order, with their byte sizes.
+struct BlobLayout {
+    size_t size[11];
+    size_t offset[11];
+    size_t total;
+};
+BlobLayout blobLayout(BlobHeader const& h) {
+    BlobLayout L{};
+    size_t const models = h.model_count;
+    L.size[0] = sizeof(rt_inode) * static_cast<size_t>(h.inode_count);
+    L.size[1] = 4 * (static_cast<size_t>(h.leaf_count) + 1);
+    L.size[2] = sizeof(rt_tri_ref) * static_cast<size_t>(h.ref_count);
+    L.size[3] = h.has_pretris ? 48 * static_cast<size_t>(h.pretri_count) : 0;
+    L.size[4] = 4 * (models + 1);
+    L.size[5] = 12 * static_cast<size_t>(h.vertex_count);
+    L.size[6] = 4 * (models + 1);
+    L.size[7] = 12 * static_cast<size_t>(h.base_tri_count);
+    L.size[8] = 4 * models;
+    L.size[9] = 48 * models;
+    L.size[10] = h.has_leaf_pretris ? 48 * static_cast<size_t>(h.ref_count) : 0;
+    size_t cursor = pad16(sizeof(BlobHeader));
+    for (int k = 0; k < 11; ++k) { L.offset[k] = cursor; cursor += pad16(L.size[k]); }
+    L.total = cursor;
+    return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_scene_serialize(const rt_scene_desc* D, void* blob, uint64_t* size) {
+    if (!D || !size) return rt_internal_fail(RT_ERR_INVALID, "rt_scene_serialize: null argument");
+    if (!D->leaf_first_ref || !D->model_pretri_begin || !D->model_vertex_begin)
+        return rt_internal_fail(RT_ERR_INVALID, "rt_scene_serialize: null offset array in description");
+    BlobHeader h{};
+    h.magic = kBlobMagic; h.version = kBlobVersion;
+    std::memcpy(h.root_box, D->root_box, sizeof h.root_box);
+    h.root_index = D->root_index;
+    h.inode_count = D->inode_count; h.leaf_count = D->leaf_count; h.ref_count = D->leaf_first_ref[D->leaf_count];
+    h.pretri_count = D->pretri_count; h.vertex_count = D->vertex_count; h.base_tri_count = D->base_tri_count;
+    h.model_count = D->model_count;
+    h.has_pretris = D->pretris ? 1u : 0u;
+    h.has_leaf_pretris = D->leaf_pretris ? 1u : 0u;
+    BlobLayout const L = blobLayout(h);
+    h.total_bytes = L.total;
+    if (!blob) { *size = L.total; return RT_OK; }                 // size query
+    if (*size < L.total) { *size = L.total; return rt_internal_fail(RT_ERR_LIMIT, "rt_scene_serialize: buffer too small"); }
+    const void* src[11] = {D->inodes, D->leaf_first_ref, D->leaf_refs, D->pretris, D->model_pretri_begin, D->vertex_normals,
+                           D->model_vertex_begin, D->base_tris, D->model_tri_begin, D->model_materials, D->leaf_pretris};
+    unsigned char* out = static_cast<unsigned char*>(blob);
+    std::memset(out, 0, pad16(sizeof h));
+    std::memcpy(out, &h, sizeof h);
+    for (int k = 0; k < 11; ++k) {
+        if (L.size[k] == 0) continue;
+        if (!src[k]) return rt_internal_fail(RT_ERR_INVALID, "rt_scene_serialize: null array in description");
+        std::memcpy(out + L.offset[k], src[k], L.size[k]);
+        std::memset(out + L.offset[k] + L.size[k], 0, pad16(L.size[k]) - L.size[k]);
+    }
+    *size = L.total;
+    return RT_OK;
+}
+
+int rt_scene_desc_from_blob(const void* blob, uint64_t size, rt_scene_desc* D) {
+    if (!blob || !D) return rt_internal_fail(RT_ERR_INVALID, "rt_scene_desc_from_blob: null argument");
+    if (size < sizeof(BlobHeader)) return rt_internal_fail(RT_ERR_INVALID, "rt_scene_desc_from_blob: buffer shorter than its header");
+    if (reinterpret_cast<uintptr_t>(blob) % 8 != 0) return rt_internal_fail(RT_ERR_INVALID, "rt_scene_desc_from_blob: buffer not 8-byte aligned");
+    BlobHeader h;
+    std::memcpy(&h, blob, sizeof h);
+    if (h.magic != kBlobMagic || h.version != kBlobVersion)
+        return rt_internal_fail(RT_ERR_INVALID, "rt_scene_desc_from_blob: not a scene buffer of this library version");
+    BlobLayout const L = blobLayout(h);
+    if (L.total != h.total_bytes || size < L.total)
+        return rt_internal_fail(RT_ERR_INVALID, "rt_scene_desc_from_blob: truncated or inconsistent buffer");
+    const unsigned char* in = static_cast<const unsigned char*>(blob);
+    auto at = [&](int k) -> const void* { return L.size[k] ? in + L.offset[k] : nullptr; };
+    std::memset(D, 0, sizeof *D);
+    std::memcpy(D->root_box, h.root_box, sizeof h.root_box);
+    D->root_index = h.root_index;
+    D->inodes = static_cast<const rt_inode*>(at(0)); D->inode_count = h.inode_count;
+    D->leaf_first_ref = static_cast<const uint32_t*>(at(1)); D->leaf_count = h.leaf_count;
+    D->leaf_refs = static_cast<const rt_tri_ref*>(at(2));
+    D->pretris = static_cast<const float*>(at(3)); D->pretri_count = h.pretri_count;
+    D->model_pretri_begin = static_cast<const uint32_t*>(at(4));
+    D->vertex_normals = static_cast<const float*>(at(5)); D->vertex_count = h.vertex_count;
+    D->model_vertex_begin = static_cast<const uint32_t*>(at(6));
+    D->base_tris = static_cast<const uint32_t*>(at(7)); D->base_tri_count = h.base_tri_count;
+    D->model_tri_begin = static_cast<const uint32_t*>(at(8));
+    D->model_materials = static_cast<const float*>(at(9)); D->model_count = h.model_count;
+    D->leaf_pretris = static_cast<const float*>(at(10));
+    if (D->leaf_first_ref[h.leaf_count] != h.ref_count)
+        return rt_internal_fail(RT_ERR_INVALID, "rt_scene_desc_from_blob: leaf offsets do not end at the reference count");
+    return RT_OK;
+}
+
+int rt_scene_create_from_blob(const void* blob, uint64_t size, int device, rt_scene** out) {
+    rt_scene_desc D;
+    int const rc = rt_scene_desc_from_blob(blob, size, &D);
+    if (rc != RT_OK) return rc;
+    return rt_scene_create(&D, device, out);
 }
 
 }  // extern "C"

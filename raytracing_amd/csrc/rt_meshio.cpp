@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -254,6 +256,8 @@ int loadPly(const std::vector<char>& data, rt_mesh_file& m) {
         if (isVertex && (ix < 0 || iy < 0 || iz < 0)) return meshFail("PLY: vertex element without x, y, z");
         if (isFace && ilist < 0) return meshFail("PLY: face element without vertex_indices");
         if (isVertex) haveNormals = inx >= 0 && iny >= 0 && inz >= 0;
+        // An element with rows but no properties would consume no data: its row loop could not end.
+        if (el.count > 0 && el.props.empty()) return meshFail("PLY: element " + el.name + " has rows but no properties");
         std::vector<double> scalars(el.props.size());
         std::vector<uint32_t> face;
         for (size_t row = 0; row < el.count; ++row) {
@@ -262,13 +266,13 @@ int loadPly(const std::vector<char>& data, rt_mesh_file& m) {
                 auto const& pr = el.props[k];
                 if (!pr.isList) { scalars[k] = format == 1 ? plyAscii(p, end, ok) : plyBinary(p, end, pr.type, ok); continue; }
                 double const cnt = format == 1 ? plyAscii(p, end, ok) : plyBinary(p, end, pr.countType, ok);
-                if (!ok || cnt < 0 || cnt > 1e6) { ok = false; break; }
+                if (!ok || !(cnt >= 0 && cnt <= 1e6)) { ok = false; break; }      // negated range test: NaN fails it
                 bool const wanted = isFace && int(k) == ilist;
                 if (wanted) face.clear();
                 for (size_t i = 0; i < static_cast<size_t>(cnt) && ok; ++i) {
                     double const v = format == 1 ? plyAscii(p, end, ok) : plyBinary(p, end, pr.itemType, ok);
                     if (wanted) {
-                        if (v < 0 || v > 4294967294.0) ok = false;
+                        if (!(v >= 0 && v <= 4294967294.0)) { ok = false; break; }
                         face.push_back(static_cast<uint32_t>(v));
                     }
                 }
@@ -302,17 +306,23 @@ const char* rt_mesh_last_error(void) { return g_meshError.c_str(); }
 int rt_mesh_load(const char* path, rt_mesh_file** out) {
     if (!path || !out) return meshFail("rt_mesh_load: null argument");
     std::vector<char> data;
-    if (!readWholeFile(path, data)) return meshFail(std::string("rt_mesh_load: cannot read ") + path);
-    rt_mesh_file* m = new rt_mesh_file;
-    bool const ply = data.size() >= 3 && std::memcmp(data.data(), "ply", 3) == 0;
-    int const rc = ply ? loadPly(data, *m) : loadObj(data, *m);
-    if (rc != 0) { delete m; return rc; }
-    if (m->positions.size() / 3 > 0xFFFFFFFEull || m->tris.size() / 3 > 0xFFFFFFFEull) {
-        delete m;
-        return meshFail("rt_mesh_load: mesh too large for 32-bit indices");
+    bool readOk = false;
+    try { readOk = readWholeFile(path, data); }
+    catch (std::bad_alloc const&) { return meshFail("rt_mesh_load: out of host memory"); }
+    if (!readOk) return meshFail(std::string("rt_mesh_load: cannot read ") + path);
+    // No exception may leave through the C ABI: a mesh too large for host memory is an error return.
+    try {
+        std::unique_ptr<rt_mesh_file> m(new rt_mesh_file);
+        bool const ply = data.size() >= 3 && std::memcmp(data.data(), "ply", 3) == 0;
+        int const rc = ply ? loadPly(data, *m) : loadObj(data, *m);
+        if (rc != 0) return rc;
+        if (m->positions.size() / 3 > 0xFFFFFFFEull || m->tris.size() / 3 > 0xFFFFFFFEull)
+            return meshFail("rt_mesh_load: mesh too large for 32-bit indices");
+        *out = m.release();
+        return 0;
     }
-    *out = m;
-    return 0;
+    catch (std::bad_alloc const&) { return meshFail("rt_mesh_load: out of host memory"); }
+    catch (...) { return meshFail("rt_mesh_load: unexpected exception"); }
 }
 
 void rt_mesh_counts(const rt_mesh_file* m, uint32_t* vertex_count, uint32_t* tri_count) {

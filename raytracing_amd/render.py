@@ -35,38 +35,64 @@ class RayTraceData:
         self.pretri_begin = scene.preprocessed_tris.tri_begin
 
 
+def _describe(d):
+    """rt_scene_desc over the arrays of a RayTraceData; returns (desc, arrays to keep alive)."""
+    t = d.bsp_tree
+    keep = dict(inodes=np.ascontiguousarray(t.inodes), first=np.ascontiguousarray(t.leaf_first_ref, np.uint32),
+                refs=np.ascontiguousarray(t.leaf_refs), pretris=np.ascontiguousarray(d.pretris, np.float32),
+                ptb=np.ascontiguousarray(d.pretri_begin, np.uint32),
+                vn=np.ascontiguousarray(d.vertex_normals, np.float32),
+                vb=np.ascontiguousarray(d.vertex_begin, np.uint32), bt=np.ascontiguousarray(d.tris, np.uint32),
+                mtb=np.ascontiguousarray(d.model_tri_begin, np.uint32),
+                mats=np.ascontiguousarray(d.materials, np.float32))
+    desc = _lib.RtSceneDesc()
+    desc.root_box[:] = [float(x) for x in t.root_box]
+    desc.root_index = t.root_index
+    desc.inodes, desc.inode_count = ptr(keep["inodes"]), t.inode_count
+    desc.leaf_first_ref, desc.leaf_refs, desc.leaf_count = ptr(keep["first"]), ptr(keep["refs"]), t.leaf_count
+    desc.pretris, desc.model_pretri_begin, desc.pretri_count = ptr(keep["pretris"]), ptr(keep["ptb"]), len(keep["pretris"])
+    desc.vertex_normals, desc.model_vertex_begin, desc.vertex_count = ptr(keep["vn"]), ptr(keep["vb"]), len(keep["vn"])
+    desc.base_tris, desc.model_tri_begin, desc.base_tri_count = ptr(keep["bt"]), ptr(keep["mtb"]), len(keep["bt"])
+    desc.model_materials, desc.model_count = ptr(keep["mats"]), len(keep["mats"])
+    return desc, keep
+
+
+def serialize_scene(ray_trace_data):
+    """rt_scene_serialize: the prepared scene as one uint8 array (what rank 0 broadcasts to the other GPUs'
+    processes)."""
+    desc, keep = _describe(ray_trace_data)
+    size = c_u64(0)
+    _lib.check(_lib.lib().rt_scene_serialize(ctypes.byref(desc), None, ctypes.byref(size)))
+    blob = np.zeros(size.value, np.uint8)
+    _lib.check(_lib.lib().rt_scene_serialize(ctypes.byref(desc), ptr(blob), ctypes.byref(size)))
+    del keep
+    return blob
+
+
 class DeviceScene:
     """A scene resident in HBM (rt_scene).  One per GPU."""
 
-    def __init__(self, ray_trace_data, device=0):
+    def __init__(self, ray_trace_data=None, device=0, blob=None):
         L = _lib.lib()
-        d = ray_trace_data
-        t = d.bsp_tree
-        # keep references alive for the duration of the call
-        keep = dict(inodes=np.ascontiguousarray(t.inodes), first=np.ascontiguousarray(t.leaf_first_ref, np.uint32),
-                    refs=np.ascontiguousarray(t.leaf_refs), pretris=np.ascontiguousarray(d.pretris, np.float32),
-                    ptb=np.ascontiguousarray(d.pretri_begin, np.uint32),
-                    vn=np.ascontiguousarray(d.vertex_normals, np.float32),
-                    vb=np.ascontiguousarray(d.vertex_begin, np.uint32), bt=np.ascontiguousarray(d.tris, np.uint32),
-                    mtb=np.ascontiguousarray(d.model_tri_begin, np.uint32),
-                    mats=np.ascontiguousarray(d.materials, np.float32))
-        desc = _lib.RtSceneDesc()
-        desc.root_box[:] = [float(x) for x in t.root_box]
-        desc.root_index = t.root_index
-        desc.inodes, desc.inode_count = ptr(keep["inodes"]), t.inode_count
-        desc.leaf_first_ref, desc.leaf_refs, desc.leaf_count = ptr(keep["first"]), ptr(keep["refs"]), t.leaf_count
-        desc.pretris, desc.model_pretri_begin, desc.pretri_count = ptr(keep["pretris"]), ptr(keep["ptb"]), len(keep["pretris"])
-        desc.vertex_normals, desc.model_vertex_begin, desc.vertex_count = ptr(keep["vn"]), ptr(keep["vb"]), len(keep["vn"])
-        desc.base_tris, desc.model_tri_begin, desc.base_tri_count = ptr(keep["bt"]), ptr(keep["mtb"]), len(keep["bt"])
-        desc.model_materials, desc.model_count = ptr(keep["mats"]), len(keep["mats"])
         self._h = _lib.vp()
-        _lib.check(L.rt_scene_create(ctypes.byref(desc), c_int(device), ctypes.byref(self._h)))
+        if blob is not None:
+            blob = np.ascontiguousarray(blob, np.uint8)
+            _lib.check(L.rt_scene_create_from_blob(ptr(blob), c_u64(blob.size), c_int(device), ctypes.byref(self._h)))
+        else:
+            desc, keep = _describe(ray_trace_data)
+            _lib.check(L.rt_scene_create(ctypes.byref(desc), c_int(device), ctypes.byref(self._h)))
+            del keep
         self.device = device
         nbytes, nodes, ltris, depth = c_u64(), c_u32(), c_u32(), c_u32()
         _lib.check(L.rt_scene_info(self._h, ctypes.byref(nbytes), ctypes.byref(nodes), ctypes.byref(ltris),
                                    ctypes.byref(depth)))
         self.device_bytes, self.node_count, self.leaf_tri_count, self.depth = (nbytes.value, nodes.value,
                                                                                ltris.value, depth.value)
+
+    @classmethod
+    def from_blob(cls, blob, device=0):
+        """rt_scene_create_from_blob: upload a scene received as bytes (see serialize_scene)."""
+        return cls(None, device, blob=blob)
 
     def close(self):
         if self._h:

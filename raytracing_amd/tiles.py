@@ -42,22 +42,54 @@ def render_sharded(render_rect, width, height, rank, world_size, buffer, bands_p
 
 
 def gather_frame(buffer, width, height, rank, world_size, bands_per_rank=4, dist=None):
-    """All ranks call this; rank 0 gets the assembled (height, width, 3) tensor, the others None.
-    One collective per frame: every rank contributes its (equal-sized, padded) band buffer."""
+    """All ranks call this; rank 0 gets the assembled (height, width, 3) tensor, the others None.  One-shot
+    form that allocates its receive buffers; a render loop should hold a FrameGatherer instead."""
+    g = FrameGatherer(width, height, rank, world_size, bands_per_rank, dist, buffer=buffer)
+    return g.gather()
+
+
+class FrameGatherer:
+    """The frame's only exchange step: every rank's finished bands go to rank 0 (torch.distributed gather:
+    RCCL point-to-point transfers over xGMI with the "nccl" backend, gloo on CPU), which puts them back into
+    frame order.  All buffers are allocated once, here."""
+
+    def __init__(self, width, height, rank, world_size, bands_per_rank=4, dist=None, device=None, buffer=None):
+        import torch
+        self.width, self.height, self.rank, self.world, self.bpr, self.dist = width, height, rank, world_size, bands_per_rank, dist
+        per = max_rank_rows(height, world_size, bands_per_rank) * width * 3
+        self.buffer = buffer if buffer is not None else torch.zeros(per, dtype=torch.float32, device=device)
+        assert self.buffer.numel() >= per
+        self.parts = self.frame = None
+        if world_size > 1 and rank == 0:
+            self.parts = [torch.empty_like(self.buffer) for _ in range(world_size)]
+            self.frame = torch.empty(height, width, 3, dtype=self.buffer.dtype, device=self.buffer.device)
+
+    def gather(self):
+        if self.world == 1:
+            return self.buffer[: self.height * self.width * 3].view(self.height, self.width, 3)
+        self.dist.gather(self.buffer, self.parts if self.rank == 0 else None, dst=0)
+        if self.rank != 0:
+            return None
+        for k in range(self.world):
+            cursor = 0
+            for _, y0, rows in rank_bands(self.height, self.world, k, self.bpr):
+                n = rows * self.width * 3
+                self.frame[y0:y0 + rows] = self.parts[k][cursor:cursor + n].view(rows, self.width, 3)
+                cursor += n
+        return self.frame
+
+
+def broadcast_bytes(payload, rank, dist, device="cpu"):
+    """One broadcast of a byte buffer from rank 0 (e.g. the prepared scene of rt_scene_serialize): rank 0
+    passes a numpy uint8 array, the other ranks None; every rank gets the bytes back as a numpy array.
+    `device` is where the collective runs ("cuda" for RCCL, "cpu" for gloo)."""
     import torch
-    if world_size == 1:
-        rows = sum(r for _, _, r in rank_bands(height, 1, 0, bands_per_rank))
-        return buffer[: rows * width * 3].view(height, width, 3)
-    gathered = torch.empty(world_size * buffer.numel(), dtype=buffer.dtype, device=buffer.device)
-    dist.all_gather_into_tensor(gathered, buffer)
-    if rank != 0:
-        return None
-    frame = torch.empty(height, width, 3, dtype=buffer.dtype, device=buffer.device)
-    per = buffer.numel()
-    for k in range(world_size):
-        cursor = k * per
-        for _, y0, rows in rank_bands(height, world_size, k, bands_per_rank):
-            n = rows * width * 3
-            frame[y0:y0 + rows] = gathered[cursor:cursor + n].view(rows, width, 3)
-            cursor += n
-    return frame
+    size = torch.tensor([payload.size if rank == 0 else 0], dtype=torch.int64, device=device)
+    dist.broadcast(size, src=0)
+    n = int(size.item())
+    if rank == 0:
+        data = torch.from_numpy(np.ascontiguousarray(payload, np.uint8)).to(device)
+    else:
+        data = torch.empty(n, dtype=torch.uint8, device=device)
+    dist.broadcast(data, src=0)
+    return payload if rank == 0 else data.cpu().numpy()

@@ -347,18 +347,27 @@ def test_full_hd_properties(builtin):
     assert np.isfinite(full).all() and (full >= 0).all()
 
 
-def test_dragon_scale_scene_full_size(oracle_lib):
+@pytest.fixture(scope="module")
+def dragon900k(oracle_lib):
+    """The 0.9 M-triangle benchmark scene on the device and in the oracle (which traverses the product's tree),
+    built once for the module."""
+    sc = scenes.dragon_scale_scene(900_000).preprocess()
+    ds = DeviceScene(RayTraceData(sc))
+    osc = oracle_lib.scene_create_with_tree(base_from_scene(sc), 1920, 1080, sc.bsp_tree)
+    yield sc, ds, osc
+    ds.close(); osc.close()
+
+
+def test_dragon_scale_scene_full_size(dragon900k):
     """The dragon-scale benchmark scene, about 0.9 M triangles.  The reference's own tree build is O(nodes x triangles)
     and cannot produce this tree in any reasonable time, so the oracle traverses the tree made by the
     product's builder (whose equality with the reference algorithm is established on small scenes in
     tests/test_host.py); hits and a rendered tile must still agree bit for bit, and the frame must not
     depend on how it is tiled."""
-    sc = scenes.dragon_scale_scene(900_000).preprocess()
+    sc, ds, osc = dragon900k
     assert 850_000 < len(sc.preprocessed_tris.tris) < 950_000 and sc.bsp_tree.oversized_leaves == 0
-    ds = DeviceScene(RayTraceData(sc))
     w, h = 1920, 1080
-    osc = oracle_lib.scene_create_with_tree(base_from_scene(sc), w, h, sc.bsp_tree)
-    try:
+    if True:
         assert ds.depth > 16                       # exercises the scratch-memory traversal stack
         # 60 000 primary rays on a pixel grid + 60 000 secondary-style rays from inside the scene box
         ys, xs = np.mgrid[0:h:6, 0:w:6]
@@ -388,8 +397,157 @@ def test_dragon_scale_scene_full_size(oracle_lib):
         assert same_bits(np.concatenate([left, right], axis=1), full)
         assert sl["segments"] + sr["segments"] == sf["segments"]
         assert np.isfinite(full).all() and full.max() > 0
+
+
+def test_dragon_scene_at_3840x2160_bands_of_eight_ranks(dragon900k, oracle_lib):
+    """Benchmark configuration 4: the same scene at 3840x2160, cut into the row bands that 8 ranks render.
+    A tile against the oracle (whose camera matrix is rebuilt for this frame size), and the frame assembled
+    from every rank's bands against the frame rendered in one piece, at 1 spp, all on this one GPU."""
+    from raytracing_amd import tiles
+    sc, ds, _ = dragon900k
+    w, h = 3840, 2160
+    p2r = sc.pixel_to_ray_transform(w, h)
+    osc = oracle_lib.scene_create_with_tree(base_from_scene(sc), w, h, sc.bsp_tree)
+    try:
+        rect = (1800, 1000, 96, 64)
+        tile, st = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=2, rect=rect, flags=_lib.RT_FLAG_COUNT_WORK))
+        otile, ost = osc.render_device_mode(osc.render_params(2, rect=rect), threads=16)
+        _assert_same_image_and_work(tile, st, otile, ost)
+    finally:
+        osc.close()
+    full, sf = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1))
+    assembled = np.zeros_like(full)
+    segments = 0
+    seen = np.zeros(h, bool)
+    for rank in range(8):
+        for _, y0, rows in tiles.rank_bands(h, 8, rank, 8):
+            band, sb = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, rect=(0, y0, w, rows)))
+            assembled[y0:y0 + rows] = band
+            segments += sb["segments"]
+            assert not seen[y0:y0 + rows].any()
+            seen[y0:y0 + rows] = True
+    assert seen.all() and same_bits(assembled, full) and segments == sf["segments"]
+    assert sf["paths"] == w * h and np.isfinite(full).all()
+
+
+def test_multi_mesh_ten_million_triangles_twelve_bounces(oracle_lib):
+    """Benchmark configuration 5: eleven instances of the 0.9 M-triangle surface (about 9.9 M triangles, 2 GB
+    in HBM), low-roughness GGX, bounce limit 12.  Hits, a tile with every work counter, and a split frame."""
+    sc = scenes.multi_mesh_scene().preprocess()
+    assert 9_000_000 < len(sc.preprocessed_tris.tris) < 11_000_000
+    ds = DeviceScene(RayTraceData(sc))
+    w, h = 1920, 1080
+    osc = oracle_lib.scene_create_with_tree(base_from_scene(sc), w, h, sc.bsp_tree)
+    try:
+        assert ds.depth > 30 and ds.device_bytes > 1.5e9
+        ys, xs = np.mgrid[0:h:6, 0:w:6]
+        xy = np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], 1).astype(np.float32)[:60_000]
+        d0 = osc.camera_rays(xy)
+        o0 = np.tile(sc.camera.position, (len(xy), 1)).astype(np.float32)
+        f, ids = osc.intersect(o0, d0)
+        _check_hits(ds.intersect(o0, d0), f, ids)
+        assert (ids[:, 0] != 0xFFFFFFFF).mean() > 0.5
+        rng = np.random.default_rng(14)
+        o1 = (f[:, 3:6] + rng.uniform(-0.3, 0.3, (len(f), 3))).astype(np.float32)
+        d1 = rng.standard_normal((len(f), 3))
+        d1 = (d1 / np.linalg.norm(d1, axis=1, keepdims=True)).astype(np.float32)
+        f1, ids1 = osc.intersect(o1, d1)
+        _check_hits(ds.intersect(o1, d1), f1, ids1)
+        rect = (900, 560, 96, 64)
+        p2r = sc.pixel_to_ray_transform(w, h)
+        tile, st = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=2, bounce_limit=12, rect=rect,
+                                            flags=_lib.RT_FLAG_COUNT_WORK))
+        otile, ost = osc.render_device_mode(osc.render_params(2, bounce_limit=12, rect=rect), threads=16)
+        _assert_same_image_and_work(tile, st, otile, ost)
+        assert st["segments"] > 2 * st["paths"]                       # long paths between the mirrors-like surfaces
+        full, sf = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, bounce_limit=12))
+        top, sa = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, bounce_limit=12, rect=(0, 0, w, 540)))
+        bottom, sb = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, bounce_limit=12, rect=(0, 540, w, 540)))
+        assert same_bits(np.concatenate([top, bottom]), full) and sa["segments"] + sb["segments"] == sf["segments"]
+        assert np.isfinite(full).all() and full.max() > 0
     finally:
         ds.close(); osc.close()
+
+
+def test_oversized_leaf_on_the_device(oracle_lib):
+    """Forty coincident triangles end up in one leaf above Leaf::MAX_TRIS (src/bsp.hpp:162; the builder's depth
+    cap): the kernels scan such a leaf in windows of 32.  Hits and a rendered tile against the oracle."""
+    tri = np.array([[0, 0, 0], [0, 0, 1], [1, 0, 0]], np.float32)
+    pos = np.concatenate([np.tile(tri, (40, 1)), np.tile(tri + np.array([0.2, -0.5, 0.2], np.float32), (3, 1))])
+    nrm = np.tile(np.array([[0, 1, 0]], np.float32), (len(pos), 1))
+    tris = np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)
+    m = S.Models()
+    m.add(S.MeshTransform(), 0, 0)
+    sc = S.Scene(S.Camera((0.4, 3, 0.4), (1.5, 0, 0), 0.8), S.Meshes([(pos, nrm, tris)]),
+                 [S.Material((0.5, 0.5, 0.5), 0.5, 0.0, (1, 2, 3))], m, inflate_mode=1)
+    sc.preprocess(max_depth=12)
+    assert sc.bsp_tree.oversized_leaves >= 1 and np.diff(sc.bsp_tree.leaf_first_ref).max() >= 40
+    ds = DeviceScene(RayTraceData(sc))
+    osc = oracle_lib.scene_create_with_tree(base_from_scene(sc), 64, 64, sc.bsp_tree)
+    try:
+        rng = np.random.default_rng(2)
+        o = np.stack([rng.uniform(-0.2, 1.2, 5000), rng.uniform(0.5, 3, 5000), rng.uniform(-0.2, 1.2, 5000)], 1).astype(np.float32)
+        d = rng.standard_normal((5000, 3)) * 0.2 + np.array([0, -1, 0])
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        for front in (True, False):
+            f, ids = osc.intersect(o, d, 1e-3, front)
+            _check_hits(ds.intersect(o, d, 1e-3, front), f, ids)
+        assert (ids[:, 1] == 0).sum() > 500 and not ((ids[:, 1] > 0) & (ids[:, 1] < 40)).any()   # always the first of the forty
+        img, st, oimg, ost = _render_both(ds, osc, sc, 64, 64, spp=3)
+        _assert_same_image_and_work(img, st, oimg, ost)
+        assert img.max() > 0
+    finally:
+        ds.close(); osc.close()
+
+
+def test_scene_from_blob_renders_the_same(builtin):
+    """rt_scene_create_from_blob (what the ranks other than 0 do with the broadcast bytes) gives a scene that
+    renders bit-identically to the one created from the description itself."""
+    from raytracing_amd.render import serialize_scene
+    sc, ds = builtin
+    other = DeviceScene.from_blob(serialize_scene(RayTraceData(sc)))
+    try:
+        assert (other.node_count, other.leaf_tri_count, other.depth, other.device_bytes) == \
+            (ds.node_count, ds.leaf_tri_count, ds.depth, ds.device_bytes)
+        p = ds.make_params(320, 200, sc.camera.position, sc.pixel_to_ray_transform(320, 200), spp=3, flags=_lib.RT_FLAG_COUNT_WORK)
+        a, sa = ds.render(p)
+        b, sb = other.render(p)
+        assert same_bits(a, b) and sa["segments"] == sb["segments"] and sa["box_tests"] == sb["box_tests"]
+    finally:
+        other.close()
+
+
+def test_russian_roulette_bit_exact_and_unbiased(builtin, oracle_lib):
+    """RT_FLAG_RUSSIAN_ROULETTE: same bits as the oracle's restatement (image and counters), fewer segments,
+    and a converged image inside the same 1/sqrt(n) envelope around the reference's 16384-spp render as the
+    plain estimator (tolerances derived in test_converged_image_matches_reference_render; roulette adds
+    variance per sample, so the bounds are the 4096-spp ones widened by 10 %)."""
+    from oracle import binding
+    sc, ds = builtin
+    cs = scenes.cornell_scene(wall_grid=8, box_grid=3)
+    dc, oc = _pair(oracle_lib, cs, 96, 64)
+    try:
+        for bounce_limit in (8, 12):
+            p = dc.make_params(96, 64, cs.camera.position, cs.pixel_to_ray_transform(96, 64), spp=6, bounce_limit=bounce_limit,
+                               seed=21, flags=_lib.RT_FLAG_COUNT_WORK | _lib.RT_FLAG_RUSSIAN_ROULETTE)
+            img, st = dc.render(p)
+            oimg, ost = oc.render_device_mode(oc.render_params(6, seed=21, bounce_limit=bounce_limit,
+                                                               flags=binding.FLAG_RUSSIAN_ROULETTE), threads=16)
+            _assert_same_image_and_work(img, st, oimg, ost)
+            plain, sp = dc.render(dc.make_params(96, 64, cs.camera.position, cs.pixel_to_ray_transform(96, 64), spp=6,
+                                                 bounce_limit=bounce_limit, seed=21))
+            assert st["segments"] < sp["segments"] and not same_bits(img, plain)
+    finally:
+        dc.close(); oc.close()
+    g = golden("builtin_converged_160x120.npz")
+    w, h = 160, 120
+    p2r = sc.pixel_to_ray_transform(w, h)
+    img, st = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=4096, seed=77, flags=_lib.RT_FLAG_RUSSIAN_ROULETTE))
+    ref = g["image"]
+    assert rel_rmse(img, ref) < 0.026 * 1.1, rel_rmse(img, ref)
+    assert abs(img.mean() / ref.mean() - 1.0) < 0.005
+    for c in range(3):
+        assert abs(img[..., c].mean() / ref[..., c].mean() - 1.0) < 0.01
 
 
 @pytest.mark.parametrize("name", ["builtin", "cornell", "displaced"])
@@ -487,10 +645,14 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RT_BENCH_SHARE_GPU="1")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "2",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "2",
            "--workload", "builtin"]
     run = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert run.returncode == 0, run.stderr[-3000:]
@@ -499,6 +661,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["spp_total"] == 4 and out["config"]["image_finite"] is True
+    assert "broadcast once" in out["config"]["parallelism"]
     assert "cpu_baseline" not in out                         # N=1 only
     # both ranks together traced the whole frame: 640x480 pixels x 4 spp paths
     assert out["config"]["segments_per_step"] > 640 * 480 * 4

@@ -75,6 +75,66 @@ def test_gather_reassembles_frame_world_size_2(width, height, bpr):
     assert result.get("ok") is True
 
 
+def _scene_worker(rank, world, port, width, height, bpr, result):
+    """The whole multi-rank frame loop with a stub renderer: rank 0 prepares the scene and broadcasts it as
+    bytes, every rank turns the bytes back into a scene description, renders its bands (the stub paints the
+    global pixel coordinates plus a checksum of the scene it received) and rank 0 gathers, twice, into the
+    same preallocated buffers."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import _lib, scenes
+    from raytracing_amd.render import RayTraceData, serialize_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        blob = None
+        if rank == 0:
+            blob = serialize_scene(RayTraceData(scenes.builtin_scene(3).preprocess()))
+        blob = tiles.broadcast_bytes(blob, rank, dist)
+        desc = _lib.RtSceneDesc()
+        _lib.check(_lib.lib().rt_scene_desc_from_blob(_lib.ptr(blob), ctypes.c_uint64(blob.size), ctypes.byref(desc)))
+        assert (desc.inode_count, desc.leaf_count, desc.model_count) == (69, 56, 30)
+        checksum = float(int(blob.astype(np.uint64).sum()) % 1000)
+        want = torch.from_numpy(_expected(width, height)) + checksum
+        gatherer = tiles.FrameGatherer(width, height, rank, world, bpr, dist)
+        frames = []
+        for step in range(2):
+            def render_rect(x0, y0, w, h, out):
+                out.copy_((want[y0:y0 + h, x0:x0 + w] + step).reshape(-1))
+                return {"segments": w * h}
+            tiles.render_sharded(render_rect, width, height, rank, world, gatherer.buffer, bpr)
+            frame = gatherer.gather()
+            frames.append(None if frame is None else frame.clone())
+        sums = torch.tensor([checksum])
+        dist.all_reduce(sums)
+        if rank == 0:
+            result["ok"] = bool(torch.equal(frames[0], want)) and bool(torch.equal(frames[1], want + 1)) \
+                and float(sums.item()) == world * checksum and gatherer.frame.data_ptr() == frame.data_ptr()
+        else:
+            assert frames == [None, None] and gatherer.parts is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_scene_render_gather_world_size_2():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    result = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_scene_worker, args=(r, 2, port, 48, 29, 3, result)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert result.get("ok") is True
+
+
 def test_single_rank_is_a_view():
     import torch
     w, h = 16, 9
