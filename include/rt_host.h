@@ -40,6 +40,18 @@ void rt_preprocess_tris(const float* inst_positions, const uint32_t* model_verte
                         const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,
                         float* out_pretris, uint32_t* out_model_pretri_begin);
 
+/* The same two steps on GPU `device`, one lane per instantiated vertex / triangle (host pointers in and out;
+ * mesh_count = number of {begin,size} pairs in the range arrays).  Bit-identical outputs to the functions
+ * above.  Return 0 or a negative rt_status (message in rt_last_error). */
+int rt_instantiate_meshes_device(int device, const float* positions, const float* normals, const uint32_t* mesh_vertex_ranges,
+                                 uint32_t mesh_count, const float* transforms, const uint32_t* model_meshes,
+                                 uint32_t model_count, float* out_positions, float* out_normals,
+                                 uint32_t* out_model_vertex_begin);
+int rt_preprocess_tris_device(int device, const float* inst_positions, const uint32_t* model_vertex_begin,
+                              const uint32_t* base_tris, const uint32_t* mesh_tri_ranges, uint32_t mesh_count,
+                              const uint32_t* model_meshes, uint32_t model_count, float* out_pretris,
+                              uint32_t* out_model_pretri_begin);
+
 /* computeBoundingBox (src/geometry.hpp:85-92) followed by the inflation of src/main.cpp:207-208
  * (inflate_mode 0: min,max *= 1.001) or an additive pad of 0.001*max extent (inflate_mode 1, for
  * scenes that do not straddle the origin). */

@@ -161,8 +161,8 @@ class InstantiatedMeshes:
         self.vertex_positions, self.vertex_normals, self.vertex_begin = positions, normals, vertex_begin
 
 
-def instantiate_meshes(vertex_positions, vertex_normals, vertex_ranges, instance_transforms, instance_meshes):
-    """src/mesh.hpp:90-138."""
+def instantiate_meshes(vertex_positions, vertex_normals, vertex_ranges, instance_transforms, instance_meshes, device=None):
+    """src/mesh.hpp:90-138.  With `device` set the work runs on that GPU (rt_instantiate_meshes_device)."""
     tr = _f32(np.stack([t.packed() for t in instance_transforms]) if len(instance_transforms) else
               np.zeros((0, 10)), (-1, 10))
     mm = _u32(instance_meshes)
@@ -171,8 +171,13 @@ def instantiate_meshes(vertex_positions, vertex_normals, vertex_ranges, instance
     pos = np.zeros((total, 3), np.float32)
     nrm = np.zeros((total, 3), np.float32)
     begin = np.zeros(len(mm) + 1, np.uint32)
-    _lib.lib().rt_instantiate_meshes(ptr(_f32(vertex_positions)), ptr(_f32(vertex_normals)), ptr(vr), ptr(tr),
-                                     ptr(mm), c_u32(len(mm)), ptr(pos), ptr(nrm), ptr(begin))
+    if device is None:
+        _lib.lib().rt_instantiate_meshes(ptr(_f32(vertex_positions)), ptr(_f32(vertex_normals)), ptr(vr), ptr(tr),
+                                         ptr(mm), c_u32(len(mm)), ptr(pos), ptr(nrm), ptr(begin))
+    else:
+        _lib.check(_lib.lib().rt_instantiate_meshes_device(c_int(device), ptr(_f32(vertex_positions)), ptr(_f32(vertex_normals)),
+                                                           ptr(vr), c_u32(len(vr)), ptr(tr), ptr(mm), c_u32(len(mm)),
+                                                           ptr(pos), ptr(nrm), ptr(begin)))
     return InstantiatedMeshes(pos, nrm, begin)
 
 
@@ -183,15 +188,21 @@ class PreprocessedTris:
         self.tris, self.tri_begin = tris, tri_begin
 
 
-def preprocess_tris(inst_positions, vertex_begin, tris, tri_ranges, instance_meshes):
-    """src/mesh.hpp:149-188: per model, {normal, v1, v1ToV3, v1ToV2} for each triangle."""
+def preprocess_tris(inst_positions, vertex_begin, tris, tri_ranges, instance_meshes, device=None):
+    """src/mesh.hpp:149-188: per model, {normal, v1, v1ToV3, v1ToV2} for each triangle.  With `device` set the
+    work runs on that GPU (rt_preprocess_tris_device)."""
     mm = _u32(instance_meshes)
     trr = _u32(tri_ranges, (-1, 2))
     total = int(trr[mm, 1].sum()) if len(mm) else 0
     out = np.zeros((total, 12), np.float32)
     begin = np.zeros(len(mm) + 1, np.uint32)
-    _lib.lib().rt_preprocess_tris(ptr(_f32(inst_positions)), ptr(_u32(vertex_begin)), ptr(_u32(tris)), ptr(trr),
-                                  ptr(mm), c_u32(len(mm)), ptr(out), ptr(begin))
+    if device is None:
+        _lib.lib().rt_preprocess_tris(ptr(_f32(inst_positions)), ptr(_u32(vertex_begin)), ptr(_u32(tris)), ptr(trr),
+                                      ptr(mm), c_u32(len(mm)), ptr(out), ptr(begin))
+    else:
+        _lib.check(_lib.lib().rt_preprocess_tris_device(c_int(device), ptr(_f32(inst_positions)), ptr(_u32(vertex_begin)),
+                                                        ptr(_u32(tris)), ptr(trr), c_u32(len(trr)), ptr(mm), c_u32(len(mm)),
+                                                        ptr(out), ptr(begin)))
     return PreprocessedTris(out, begin)
 
 
@@ -262,14 +273,15 @@ class Scene:
         self.bounding_box = None
         self.bsp_tree = None
 
-    def preprocess(self, max_leaf_tris=32, max_depth=60, threads=0):
+    def preprocess(self, max_leaf_tris=32, max_depth=60, threads=0, device=None):
+        """`device`: run instancing and triangle preprocessing on that GPU instead of the host (same arrays)."""
         self.preprocessed_materials = np.stack([preprocess_material(m) for m in self.materials])
         self.instantiated_meshes = instantiate_meshes(self.meshes.vertex_positions, self.meshes.vertex_normals,
                                                       self.meshes.vertex_ranges, self.models.mesh_transforms,
-                                                      self.models.meshes)
+                                                      self.models.meshes, device)
         im = self.instantiated_meshes
         self.preprocessed_tris = preprocess_tris(im.vertex_positions, im.vertex_begin, self.meshes.tris,
-                                                 self.meshes.tri_ranges, self.models.meshes)
+                                                 self.meshes.tri_ranges, self.models.meshes, device)
         self.bounding_box = scene_bounding_box(im.vertex_positions, self.inflate_mode)
         self.bsp_tree = BSPTree(im.vertex_positions, im.vertex_begin, self.meshes.tris, self.meshes.tri_ranges,
                                 self.models.meshes, self.bounding_box, max_leaf_tris, max_depth, threads)

@@ -500,6 +500,39 @@ def test_oversized_leaf_on_the_device(oracle_lib):
         ds.close(); osc.close()
 
 
+def test_instancing_and_triangle_preprocessing_on_the_device():
+    """rt_instantiate_meshes_device / rt_preprocess_tris_device (src/mesh.hpp:90-188, src/geometry.hpp:77-82 on the
+    GPU) against the host functions and against the arrays the compiled reference produced for its built-in
+    scene (golden), bit for bit; several instances, rotations, anisotropic scales, and an empty model list."""
+    g = golden("builtin_scene.npz")
+    sc = scene_from_golden(g)
+    host = scene_from_golden(g).preprocess()
+    sc.preprocess(device=0)
+    assert same_bits(sc.instantiated_meshes.vertex_positions, g["pre_positions"])
+    assert same_bits(sc.instantiated_meshes.vertex_normals, g["pre_normals"])
+    assert same_bits(sc.preprocessed_tris.tris, g["pre_pretris"])
+    assert np.array_equal(sc.instantiated_meshes.vertex_begin, host.instantiated_meshes.vertex_begin)
+    assert np.array_equal(sc.preprocessed_tris.tri_begin, host.preprocessed_tris.tri_begin)
+    rng = np.random.default_rng(6)
+    big = scenes.dragon_scale_scene(60_000, copies=5)
+    for t in big.models.mesh_transforms:                       # anisotropic scales and arbitrary rotations
+        t.scale = rng.uniform(0.3, 2.5, 3).astype(np.float32)
+        q = rng.standard_normal(4)
+        t.orientation = (q / np.linalg.norm(q)).astype(np.float32)
+    a = S.instantiate_meshes(big.meshes.vertex_positions, big.meshes.vertex_normals, big.meshes.vertex_ranges,
+                             big.models.mesh_transforms, big.models.meshes)
+    b = S.instantiate_meshes(big.meshes.vertex_positions, big.meshes.vertex_normals, big.meshes.vertex_ranges,
+                             big.models.mesh_transforms, big.models.meshes, device=0)
+    assert len(a.vertex_positions) > 100_000
+    assert same_bits(a.vertex_positions, b.vertex_positions) and same_bits(a.vertex_normals, b.vertex_normals)
+    assert np.array_equal(a.vertex_begin, b.vertex_begin)
+    ta = S.preprocess_tris(a.vertex_positions, a.vertex_begin, big.meshes.tris, big.meshes.tri_ranges, big.models.meshes)
+    tb = S.preprocess_tris(a.vertex_positions, a.vertex_begin, big.meshes.tris, big.meshes.tri_ranges, big.models.meshes, device=0)
+    assert same_bits(ta.tris, tb.tris) and np.array_equal(ta.tri_begin, tb.tri_begin)
+    none = S.instantiate_meshes(big.meshes.vertex_positions, big.meshes.vertex_normals, big.meshes.vertex_ranges, [], [], device=0)
+    assert len(none.vertex_positions) == 0 and list(none.vertex_begin) == [0]
+
+
 def test_scene_from_blob_renders_the_same(builtin):
     """rt_scene_create_from_blob (what the ranks other than 0 do with the broadcast bytes) gives a scene that
     renders bit-identically to the one created from the description itself."""
