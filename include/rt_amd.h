@@ -110,7 +110,8 @@ typedef struct {
     float camera_position[3];
     float pixel_to_ray[9];        /* column-major mat3 {right, down, o}, src/camera.hpp:45 */
     uint32_t flags;
-    uint32_t max_batch_paths;     /* 0 = default */
+    uint32_t max_batch_paths;     /* paths traced together; 0 = as many as the call has, within 2^30 paths and half
+                                   * of the GPU's memory (76 bytes of workspace per path) */
 } rt_render_params;
 
 typedef struct {

@@ -26,7 +26,7 @@
 #define RT_STACK_MAX 64          // per-lane traversal stack entries (tree depth bound)
 #define RT_BLOCK 256
 #define RT_STAGE 256u                // survivors staged per wave before one append to the next queue
-#define RT_LDS_STACK_DEPTH 16   // traversal stack entries kept in LDS (16 KiB per block); deeper ones spill to scratch
+#define RT_LDS_STACK_DEPTH 22   // traversal stack entries kept in LDS (22 KiB per block: seven blocks fill a CU's 160 KiB); deeper ones spill to scratch
 
 namespace {
 
@@ -547,13 +547,43 @@ struct PathState {
     uint32_t* counts;     // counts[b] = number of paths entering bounce b
 };
 
+// Path slot p of a batch (slot = sampleInBatch * pixels + p) belongs to the pixel at (x, y) of the rendered
+// rectangle.  The part of the rectangle that 8x8 tiles cover is numbered tile by tile, so that the 64 lanes
+// of a wave start on an 8x8 block of pixels (their rays stay close together in the tree: fewer distinct
+// cache lines per load, fewer idle lanes); the strip right of it and the strip below it follow in row order.
+// The pixel's own index y*width+x keys the sampler, so the image does not depend on this numbering.
+__device__ __forceinline__ void slotPixel(uint32_t p, uint32_t w, uint32_t h, uint32_t& x, uint32_t& y) {
+    uint32_t const w8 = w & ~7u, h8 = h & ~7u;
+    uint32_t const tiled = w8 * h8;
+    if (p < tiled) {
+        uint32_t const tile = p >> 6, in = p & 63u, tilesX = w8 >> 3;
+        uint32_t const ty = tile / tilesX, tx = tile - ty * tilesX;
+        x = (tx << 3) + (in & 7u);
+        y = (ty << 3) + (in >> 3);
+        return;
+    }
+    uint32_t q = p - tiled;
+    uint32_t const right = (w - w8) * h;
+    if (q < right) {
+        uint32_t const rw = w - w8;
+        y = q / rw;
+        x = w8 + (q - y * rw);
+        return;
+    }
+    q -= right;
+    y = h8 + q / w8;
+    x = q - (q / w8) * w8;
+}
+
 // Camera rays, src/render.hpp:225-228: jittered sample position, direction = normalize(M * (sx, sy, 1)).
 __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P, uint32_t pixels, uint32_t sampleBase,
                                                      uint32_t paths) {
     uint32_t const stride = gridDim.x * blockDim.x;
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < paths; id += stride) {
         uint32_t const sLocal = id / pixels, p = id - sLocal * pixels;
-        uint32_t const px = R.x0 + p % R.w, py = R.y0 + p / R.w;
+        uint32_t lx, ly;
+        slotPixel(p, R.w, R.h, lx, ly);
+        uint32_t const px = R.x0 + lx, py = R.y0 + ly;
         uint32_t r0, r1, r2;
         philox(py * R.width + px, sampleBase + sLocal, 0u, R.key0, R.key1, r0, r1, r2);
         float const sx = static_cast<float>(px) + unitFloat(r0);
@@ -652,7 +682,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
                     V3 const p2 = crossU(normal, p1);
                     // GGX sampling of the half vector, src/render.hpp:145-153
                     uint32_t const sLocal = slot / pixels, p = slot - sLocal * pixels;
-                    uint32_t const px = R.x0 + p % R.w, py = R.y0 + p / R.w;
+                    uint32_t lx, ly;
+                    slotPixel(p, R.w, R.h, lx, ly);
+                    uint32_t const px = R.x0 + lx, py = R.y0 + ly;
                     uint32_t r0, r1, r2;
                     philox(py * R.width + px, sampleBase + sLocal, bounce + 1u, R.key0, R.key1, r0, r1, r2);
                     float const thetaParam = unitFloat(r0);
@@ -745,6 +777,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
 // reference's `colour += rayTrace(...)` loop, src/render.hpp:224-230), and on the last batch divides
 // by the sample count (src/render.hpp:231) and writes the image.
 __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathState P, float* __restrict__ accum, uint32_t pixels,
+                                                         uint32_t rectW, uint32_t rectH,
                                                          uint32_t samplesInBatch, uint32_t bounceCount, int last,
                                                          float sppF, float* __restrict__ out,
                                                          Counters* __restrict__ gc) {
@@ -757,9 +790,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathState P, float* __r
             r = r + C.y; g = g + C.z; b = b + C.w;
         }
         if (last) {
-            out[3 * static_cast<size_t>(p)] = r / sppF;
-            out[3 * static_cast<size_t>(p) + 1] = g / sppF;
-            out[3 * static_cast<size_t>(p) + 2] = b / sppF;
+            uint32_t x, y;
+            slotPixel(p, rectW, rectH, x, y);
+            size_t const o = 3 * (static_cast<size_t>(y) * rectW + x);       // row-major image of the rectangle
+            out[o] = r / sppF;
+            out[o + 1] = g / sppF;
+            out[o + 2] = b / sppF;
         }
         else {
             accum[3 * static_cast<size_t>(p)] = r;
@@ -915,6 +951,8 @@ int residentBlocks(const rt_scene* s, Kernel kernel) {
 }
 
 int persistentGrid(int residentCap, uint64_t items) {
+    static bool const full = std::getenv("RT_AMD_FULL_GRID") != nullptr;     // measurement aid
+    if (full) return residentCap;
     uint64_t const blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
     return static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(blocks, static_cast<uint64_t>(residentCap))));
 }
@@ -969,7 +1007,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     struct HNode { float lo[3], hi[3]; int32_t index; uint32_t aux; };
     static_assert(sizeof(HNode) == 32, "node record must be 32 bytes");
     std::vector<HNode> nodes;
-    nodes.reserve(2 * static_cast<size_t>(D->inode_count) + 1);
+    nodes.reserve(2 * static_cast<size_t>(D->inode_count) + 2);
     auto leafRecord = [&](int32_t refIndex, HNode& n) -> int {
         uint32_t const leaf = static_cast<uint32_t>(-(refIndex + 1));
         if (leaf >= D->leaf_count) return fail(RT_ERR_INVALID, "rt_scene_create: leaf index out of range");
@@ -985,6 +1023,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
         std::memcpy(root.lo, D->root_box, 12);
         std::memcpy(root.hi, D->root_box + 3, 12);
         nodes.push_back(root);
+        nodes.push_back(HNode{});          // padding: child pairs then start at even slots, one pair per 64-byte line
         struct Item { uint32_t nodeSlot; int32_t refIndex; uint32_t depth; };
         std::vector<Item> todo;
         todo.push_back({0u, D->root_index, 0u});
@@ -1187,7 +1226,7 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
         int const last = done + nb >= p->spp;
         mark(3);
         hipLaunchKernelGGL(k_accumulate, dim3(static_cast<unsigned>((pixels + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK),
-                           0, st, P, W.accum, static_cast<uint32_t>(pixels), nb, bounceCount, last,
+                           0, st, P, W.accum, static_cast<uint32_t>(pixels), p->w, p->h, nb, bounceCount, last,
                            static_cast<float>(p->spp), d_out, gc);
         mark(-1);
         ++batches;
@@ -1212,6 +1251,13 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
             stats->ms_raygen = acc[0]; stats->ms_trace = acc[1]; stats->ms_shade = acc[2]; stats->ms_accumulate = acc[3];
         }
         stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (std::getenv("RT_AMD_DEBUG")) {           // queue sizes of the last batch, per bounce
+            uint32_t counts[32] = {};
+            (void)hipMemcpy(counts, P.counts, sizeof(uint32_t) * std::min<uint32_t>(bounceCount + 1, 32), hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "rt_amd: paths entering each bounce of the last batch:");
+            for (uint32_t b = 0; b < std::min<uint32_t>(bounceCount + 1, 32); ++b) std::fprintf(stderr, " %u", counts[b]);
+            std::fprintf(stderr, "\n");
+        }
     }
     return RT_OK;
 }
@@ -1322,24 +1368,46 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
         int const rcs = adoptStream(s, st);
         if (rcs != RT_OK) return rcs;
         uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
-        uint64_t const maxPaths = p->max_batch_paths ? p->max_batch_paths : (16ull << 20);
-        uint32_t const spb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(p->spp, maxPaths / pixels)));
-        uint64_t const batchPaths = pixels * spb;
-        if (batchPaths > 0xFFFFFFF0ull) return fail(RT_ERR_LIMIT, "rt_render: rectangle too large for one batch");
+        // Paths per batch.  Every bounce of a batch is one launch whose last rays set its duration (a few hundred
+        // microseconds for the slowest line of a deep tree, however few lines are left), so batches should be as
+        // large as memory allows: 76 bytes of HBM per path slot.  Default: the whole call in one batch, up to
+        // 2^30 paths (82 GB) and half of the device's memory; halved again for as long as the allocation fails.
+        uint64_t maxPaths = p->max_batch_paths;
+        if (const char* text = std::getenv("RT_AMD_BATCH_PATHS")) maxPaths = std::max<uint64_t>(1, std::strtoull(text, nullptr, 10));
+        bool const automatic = maxPaths == 0;
+        if (automatic) {
+            size_t freeBytes = 0, totalBytes = 0;
+            maxPaths = 1ull << 30;
+            if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && totalBytes > 0)
+                maxPaths = std::min<uint64_t>(maxPaths, std::max<uint64_t>(16ull << 20, totalBytes / 2 / 76));
+        }
         Workspace& W = s->ws;
-        if (W.paths < batchPaths || W.pixels < pixels) {
+        uint32_t spb = 0;
+        for (;;) {
+            spb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(p->spp, maxPaths / pixels)));
+            uint64_t const batchPaths = pixels * spb;
+            if (batchPaths > 0xFFFFFFF0ull) return fail(RT_ERR_LIMIT, "rt_render: rectangle too large for one batch");
+            if (W.paths >= batchPaths && W.pixels >= pixels) break;
             HIP_TRY(hipStreamSynchronize(st));
             freeWorkspace(s);
             void* ptr = nullptr;
-            HIP_TRY(hipMalloc(&ptr, batchPaths * 16)); W.A = static_cast<float4*>(ptr);
-            HIP_TRY(hipMalloc(&ptr, batchPaths * 16)); W.B = static_cast<float4*>(ptr);
-            HIP_TRY(hipMalloc(&ptr, batchPaths * 16)); W.C = static_cast<float4*>(ptr);
-            HIP_TRY(hipMalloc(&ptr, batchPaths * 16)); W.hit = static_cast<float4*>(ptr);
-            HIP_TRY(hipMalloc(&ptr, batchPaths * 4)); W.q0 = static_cast<uint32_t*>(ptr);
-            HIP_TRY(hipMalloc(&ptr, batchPaths * 4)); W.q1 = static_cast<uint32_t*>(ptr);
-            HIP_TRY(hipMalloc(&ptr, pixels * 12)); W.accum = static_cast<float*>(ptr);
-            W.paths = batchPaths;
-            W.pixels = pixels;
+            hipError_t e = hipMalloc(&ptr, batchPaths * 16); W.A = static_cast<float4*>(ptr); ptr = nullptr;
+            if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 16); W.B = static_cast<float4*>(ptr); ptr = nullptr; }
+            if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 16); W.C = static_cast<float4*>(ptr); ptr = nullptr; }
+            if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 16); W.hit = static_cast<float4*>(ptr); ptr = nullptr; }
+            if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 4); W.q0 = static_cast<uint32_t*>(ptr); ptr = nullptr; }
+            if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 4); W.q1 = static_cast<uint32_t*>(ptr); ptr = nullptr; }
+            if (e == hipSuccess) { e = hipMalloc(&ptr, pixels * 12); W.accum = static_cast<float*>(ptr); ptr = nullptr; }
+            if (e == hipSuccess) {
+                W.paths = batchPaths;
+                W.pixels = pixels;
+                break;
+            }
+            freeWorkspace(s);
+            (void)hipGetLastError();
+            if (!automatic || spb == 1 || e != hipErrorOutOfMemory)
+                return fail(RT_ERR_HIP, std::string("rt_render: workspace allocation failed: ") + hipGetErrorString(e));
+            maxPaths = std::max<uint64_t>(pixels, batchPaths / 2);
         }
         return renderCore(s, p, d_out, stats, st, W, spb, (p->flags & RT_FLAG_PROFILE_KERNELS) != 0);
     });
