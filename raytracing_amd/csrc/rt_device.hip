@@ -26,7 +26,7 @@
 #define RT_STACK_MAX 64          // per-lane traversal stack entries (tree depth bound)
 #define RT_BLOCK 256
 #define RT_STAGE 256u                // survivors staged per wave before one append to the next queue
-#define RT_LDS_STACK_DEPTH 22   // traversal stack entries kept in LDS (22 KiB per block: seven blocks fill a CU's 160 KiB); deeper ones spill to scratch
+#define RT_LDS_STACK_DEPTH 20   // traversal stack entries kept in LDS (20 KiB per block: eight blocks fill a CU's 160 KiB); deeper ones spill to scratch
 
 namespace {
 
@@ -193,6 +193,18 @@ __device__ __forceinline__ bool originInsideRule(int filterBits, float mu, V3 o,
     return inside && mu < INFINITY && (onPlane || (filterBits & 4) != 0);
 }
 
+// Diagnostic build only (-DRT_DIAG, make diag): per-phase cycle and lane-occupancy tallies of traceStream.
+#ifdef RT_DIAG
+__device__ unsigned long long g_diag[16];
+#define DIAG_T(var) unsigned long long var = clock64()
+#define DIAG_ADD(slot, value) diag[slot] += (value)
+#define DIAG_LANES(iterSlot, laneSlot) do { diag[iterSlot] += 1; diag[laneSlot] += __popcll(__ballot(true)); } while (0)
+#else
+#define DIAG_T(var)
+#define DIAG_ADD(slot, value)
+#define DIAG_LANES(iterSlot, laneSlot)
+#endif
+
 struct HitRec {
     float t, u, v;
     uint32_t ref;       // index of the leaf triangle record, 0xFFFFFFFF = miss
@@ -254,8 +266,12 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     float mu = INFINITY;
     HitRec best;
     best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
+#ifdef RT_DIAG
+    unsigned long long diag[16] = {};
+#endif
 
     for (;;) {
+        DIAG_T(t0);
         // ---- refill idle lanes ------------------------------------------------------------------
         unsigned long long idle = __ballot(!active);
         while (idle != 0ull && !drained) {
@@ -289,6 +305,9 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             idle = __ballot(!active);
         }
         if (__ballot(active) == 0ull) break;
+        DIAG_T(t1);
+        DIAG_ADD(0, t1 - t0);
+        DIAG_ADD(12, 1); DIAG_ADD(13, __popcll(__ballot(active)));
         if (!active) continue;
 
         // ---- phase 1: interior nodes until a leaf is reached or nothing is left ------------------
@@ -299,6 +318,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
         // that they count exactly the visits of the reference.
         while (cur != NONE && pend3 == NONE) {
             if (!COUNT) { if (__ballot(pend1 == NONE) == 0ull) break; }
+            DIAG_LANES(6, 7);
             float4 const q0 = S.nodes[2 * cur];
             float4 const q1 = S.nodes[2 * cur + 1];
             V3 const nlo = mk(q0.x, q0.y, q0.z), nhi = mk(q0.w, q1.x, q1.y);
@@ -361,6 +381,8 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             }
         }
 
+        DIAG_T(t2);
+        DIAG_ADD(1, t2 - t1);
         uint32_t leafFirst = 0, leafCount = 0;
         V3 lo = mk(0.0f, 0.0f, 0.0f), hi = lo;
         if (pend1 != NONE) {
@@ -381,12 +403,15 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
         // that all lanes share: it would otherwise be issued for a handful of lanes on almost every
         // triangle.
         bool has = false;
+        DIAG_T(t3);
+        DIAG_ADD(2, t3 - t2);
         if (leafCount != 0) {
             if (COUNT) { c.leafVisits++; c.trisTested += leafCount; }
             for (uint32_t window = 0; window < leafCount; window += 32u) {
                 uint32_t const windowEnd = min(leafCount, window + 32u);
                 uint32_t candidates = 0;
                 for (uint32_t j = window; j < windowEnd; ++j) {
+                    DIAG_LANES(8, 9);
                     float4 const* tp = S.leafTris + 3 * static_cast<size_t>(leafFirst + j);
                     // The facing test needs only the first 16 bytes of the record; lanes that fail it
                     // do not fetch the rest.
@@ -416,6 +441,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                     candidates |= 1u << (j - window);
                 }
                 while (candidates != 0u) {
+                    DIAG_LANES(10, 11);
                     uint32_t const j = window + static_cast<uint32_t>(__ffs(static_cast<int>(candidates)) - 1);
                     candidates &= candidates - 1u;
                     float4 const* tp = S.leafTris + 3 * static_cast<size_t>(leafFirst + j);
@@ -438,12 +464,20 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 }
             }
         }
+        DIAG_T(t4);
+        DIAG_ADD(3, t4 - t3);
         // First leaf with an accepted hit ends the search (src/bsp.hpp:136-138); so does running out of nodes.
         if (has || (cur == NONE && pend1 == NONE)) {
             store(line, best, o, d);
             active = false;
         }
+        DIAG_T(t5);
+        DIAG_ADD(4, t5 - t4);
     }
+#ifdef RT_DIAG
+    if (lane == 0)
+        for (int k = 0; k < 16; ++k) if (diag[k]) atomicAdd(&g_diag[k], diag[k]);
+#endif
 }
 
 // Philox-4x32-10 keyed by the render seed; counter = (pixel index, sample index, dimension pair, 0).
@@ -936,16 +970,17 @@ void freeWorkspace(rt_scene* s) {
 // static share of the line stream assumes all waves run concurrently), so the cap is the kernel's own
 // occupancy.
 template <class Kernel>
-int residentBlocks(const rt_scene* s, Kernel kernel) {
+int residentBlocks(const rt_scene* s, Kernel kernel, bool deepTree) {
     int perCu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, RT_BLOCK, 0) != hipSuccess || perCu <= 0) perCu = 4;
     if (std::getenv("RT_AMD_DEBUG"))
         std::fprintf(stderr, "rt_amd: persistent kernel %p: %d resident blocks per CU\n", reinterpret_cast<const void*>(kernel), perCu);
-    // Seven resident blocks (28 waves) per CU: measured best overall.  With eight, the 32 KB L1 of a
-    // CU is shared by more lines at once and its hit rate drops (-3 % on a 4 k-triangle scene, +0.4 %
-    // on a 0.9 M-triangle one); six or fewer lose latency hiding on the large scenes.
-    // RT_AMD_BLOCKS_PER_CU overrides the cap for tuning.
-    int cap = 7;
+    // Trees deeper than the LDS stack (large scenes: most node and triangle loads miss L1 whatever the
+    // occupancy) run eight resident blocks per CU, which is what the 20 KiB of stack per block allow:
+    // +2.6 % on a 0.9 M-triangle scene over seven.  Shallow trees (small scenes, L1-resident) run seven: with
+    // eight, the 32 KB L1 of a CU is shared by more lines at once and its hit rate drops (-2.4 % on a
+    // 4 k-triangle scene).  RT_AMD_BLOCKS_PER_CU overrides the cap for tuning.
+    int cap = deepTree ? 8 : 7;
     if (const char* text = std::getenv("RT_AMD_BLOCKS_PER_CU")) cap = std::max(1, std::atoi(text));
     return s->cuCount * std::min(perCu, cap);
 }
@@ -1146,14 +1181,14 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     s->leafTriCount = refCount;
     s->depth = maxDepth;
     s->modelCount = D->model_count;
-    s->gridTrace[0][0] = residentBlocks(s, k_trace<false, false>);
-    s->gridTrace[0][1] = residentBlocks(s, k_trace<false, true>);
-    s->gridTrace[1][0] = residentBlocks(s, k_trace<true, false>);
-    s->gridTrace[1][1] = residentBlocks(s, k_trace<true, true>);
-    s->gridIntersect[0][0] = residentBlocks(s, k_intersect<false, false>);
-    s->gridIntersect[0][1] = residentBlocks(s, k_intersect<false, true>);
-    s->gridIntersect[1][0] = residentBlocks(s, k_intersect<true, false>);
-    s->gridIntersect[1][1] = residentBlocks(s, k_intersect<true, true>);
+    s->gridTrace[0][0] = residentBlocks(s, k_trace<false, false>, false);
+    s->gridTrace[0][1] = residentBlocks(s, k_trace<false, true>, true);
+    s->gridTrace[1][0] = residentBlocks(s, k_trace<true, false>, false);
+    s->gridTrace[1][1] = residentBlocks(s, k_trace<true, true>, true);
+    s->gridIntersect[0][0] = residentBlocks(s, k_intersect<false, false>, false);
+    s->gridIntersect[0][1] = residentBlocks(s, k_intersect<false, true>, true);
+    s->gridIntersect[1][0] = residentBlocks(s, k_intersect<true, false>, false);
+    s->gridIntersect[1][1] = residentBlocks(s, k_intersect<true, true>, true);
     int const rc = bindStaticWorkspace(s);
     if (rc != RT_OK) return rc;
     *out = holder.release();
@@ -1450,6 +1485,20 @@ int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* 
     HIP_TRY(hipMemcpy(out_rgb, s->wsOut, pixels * 12, hipMemcpyDeviceToHost));
     return RT_OK;
 }
+
+#ifdef RT_DIAG
+// Diagnostic build only: the tallies of traceStream since the last reset.  [0..4] wave cycles in refill, node
+// walk, leaf fetch, triangle scan, store; [6,7] walk iterations and lanes active in them; [8,9] the same for the
+// first triangle pass, [10,11] for the second; [12,13] outer iterations and lanes holding a line.
+int rt_diag_read(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), zero, sizeof zero) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // Test hook: evaluates one scalar building block on the GPU for n inputs (see k_selftest).
 int rt_selftest_math(int op, const float* a, const float* b, uint32_t n, float* out) {
