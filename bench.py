@@ -246,8 +246,8 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     stream = torch.cuda.current_stream().cuda_stream
-    # One rectangle per GPU when alone; 8 bands per rank otherwise (tools/band_balance.py: max/mean rank load
-    # 1.03 at 8 ranks on the 0.9M-triangle scene, 1.07 with 4).
+    # One rectangle per GPU when alone; otherwise 8 bands per rank, dealt round-robin and rendered by one call
+    # per frame (tools/band_balance.py: max/mean rank load 1.03 at 8 ranks on the 0.9M-triangle scene, 1.07 with 4).
     bands_per_rank = 1 if world == 1 else 8
     render_buf = torch.zeros(tiles.max_rank_rows(height, world, bands_per_rank) * width * 3, dtype=torch.float32, device="cuda")
     gatherer = tiles.FrameGatherer(width, height, rank, world, bands_per_rank, dist,
@@ -255,11 +255,12 @@ def main():
     extra = _lib.RT_FLAG_RUSSIAN_ROULETTE if args.roulette else 0
 
     def step(seed, flags, spp_step):
-        def render_rect(x0, y0, w, h, out):
-            p = ds.make_params(width, height, cam_pos, p2r, spp=spp_step, bounce_limit=bounce_limit,
-                               seed=seed, rect=(x0, y0, w, h), flags=flags | extra)
+        def render_rows(y0, rows, row_group, row_stride, out):
+            p = ds.make_params(width, height, cam_pos, p2r, spp=spp_step, bounce_limit=bounce_limit, seed=seed,
+                               rect=(0, y0, width, rows), flags=flags | extra, row_group=row_group, row_stride=row_stride)
             return ds.render_device(p, out, stream=stream)
-        st = tiles.render_sharded(render_rect, width, height, rank, world, render_buf, bands_per_rank)
+        # all of this rank's bands in one call (interleaved row groups)
+        st = tiles.render_interleaved(render_rows, width, height, rank, world, render_buf, bands_per_rank)
         if share_gpu and world > 1:
             torch.cuda.synchronize()
             gatherer.buffer.copy_(render_buf.cpu())

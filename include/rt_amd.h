@@ -112,6 +112,11 @@ typedef struct {
     uint32_t flags;
     uint32_t max_batch_paths;     /* paths traced together; 0 = as many as the call has, within 2^30 paths and half
                                    * of the GPU's memory (76 bytes of workspace per path) */
+    /* Interleaved row groups, for sharding one frame over several GPUs with a single call per GPU: with
+     * row_stride > 1, row r of the output (0 <= r < h) is image row y0 + (r / row_group) * row_group * row_stride
+     * + r % row_group, i.e. this call renders every row_stride-th group of row_group rows, starting at y0.
+     * row_stride 0 or 1: the plain rectangle. */
+    uint32_t row_group, row_stride;
 } rt_render_params;
 
 typedef struct {

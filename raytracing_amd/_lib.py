@@ -44,7 +44,7 @@ class RtRenderParams(ctypes.Structure):
     _fields_ = [("width", c_u32), ("height", c_u32), ("x0", c_u32), ("y0", c_u32), ("w", c_u32), ("h", c_u32),
                 ("spp", c_u32), ("bounce_limit", c_u32), ("t_min", c_f32), ("seed", c_u64),
                 ("camera_position", c_f32 * 3), ("pixel_to_ray", c_f32 * 9), ("flags", c_u32),
-                ("max_batch_paths", c_u32)]
+                ("max_batch_paths", c_u32), ("row_group", c_u32), ("row_stride", c_u32)]
 
 
 class RtStats(ctypes.Structure):

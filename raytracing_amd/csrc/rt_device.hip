@@ -83,6 +83,7 @@ struct RenderConst {
     float tMin;
     uint32_t key0, key1;
     uint32_t roulette;          // RT_FLAG_RUSSIAN_ROULETTE
+    uint32_t rowGroup, rowSkip; // interleaved row groups: image row = y0 + r + (r / rowGroup) * rowSkip (rowSkip 0: plain rectangle)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P,
         uint32_t const sLocal = id / pixels, p = id - sLocal * pixels;
         uint32_t lx, ly;
         slotPixel(p, R.w, R.h, lx, ly);
-        uint32_t const px = R.x0 + lx, py = R.y0 + ly;
+        uint32_t const px = R.x0 + lx, py = R.y0 + ly + (R.rowSkip ? (ly / R.rowGroup) * R.rowSkip : 0u);
         uint32_t r0, r1, r2;
         philox(py * R.width + px, sampleBase + sLocal, 0u, R.key0, R.key1, r0, r1, r2);
         float const sx = static_cast<float>(px) + unitFloat(r0);
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
                     uint32_t const sLocal = slot / pixels, p = slot - sLocal * pixels;
                     uint32_t lx, ly;
                     slotPixel(p, R.w, R.h, lx, ly);
-                    uint32_t const px = R.x0 + lx, py = R.y0 + ly;
+                    uint32_t const px = R.x0 + lx, py = R.y0 + ly + (R.rowSkip ? (ly / R.rowGroup) * R.rowSkip : 0u);
                     uint32_t r0, r1, r2;
                     philox(py * R.width + px, sampleBase + sLocal, bounce + 1u, R.key0, R.key1, r0, r1, r2);
                     float const thetaParam = unitFloat(r0);
@@ -1216,6 +1217,9 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
     R.bounceLimit = p->bounce_limit; R.tMin = p->t_min;
     R.key0 = static_cast<uint32_t>(p->seed); R.key1 = static_cast<uint32_t>(p->seed >> 32);
     R.roulette = (p->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u;
+    bool const interleaved = p->row_stride > 1u && p->row_group > 0u;
+    R.rowGroup = interleaved ? p->row_group : 1u;
+    R.rowSkip = interleaved ? p->row_group * (p->row_stride - 1u) : 0u;
 
     bool const countWork = (p->flags & RT_FLAG_COUNT_WORK) != 0;
     size_t eventsUsed = 0;
@@ -1300,7 +1304,12 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
 int checkRenderParams(const rt_scene* s, const rt_render_params* p, const float* d_out) {
     if (!s || !p || !d_out) return fail(RT_ERR_INVALID, "rt_render: null argument");
     if (p->w == 0 || p->h == 0 || p->spp == 0) return fail(RT_ERR_INVALID, "rt_render: empty rectangle or zero spp");
-    if (static_cast<uint64_t>(p->x0) + p->w > p->width || static_cast<uint64_t>(p->y0) + p->h > p->height)
+    uint64_t lastRow = static_cast<uint64_t>(p->y0) + p->h - 1;
+    if (p->row_stride > 1u) {
+        if (p->row_group == 0u) return fail(RT_ERR_INVALID, "rt_render: row_stride without row_group");
+        lastRow = static_cast<uint64_t>(p->y0) + (p->h - 1) + static_cast<uint64_t>((p->h - 1) / p->row_group) * p->row_group * (p->row_stride - 1u);
+    }
+    if (static_cast<uint64_t>(p->x0) + p->w > p->width || lastRow >= p->height)
         return fail(RT_ERR_INVALID, "rt_render: rectangle outside the image");
     if (static_cast<uint64_t>(p->width) * p->height > 0xFFFFFFFFull)
         return fail(RT_ERR_LIMIT, "rt_render: more than 2^32 pixels");
@@ -1313,7 +1322,7 @@ int checkRenderParams(const rt_scene* s, const rt_render_params* p, const float*
 extern "C" {
 
 const char* rt_last_error(void) { return g_lastError.c_str(); }
-uint32_t rt_abi_version(void) { return 4; }
+uint32_t rt_abi_version(void) { return 5; }
 
 int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     return guarded("rt_scene_create", [&] { return sceneCreate(D, device, out); });

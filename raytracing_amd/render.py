@@ -126,7 +126,7 @@ class DeviceScene:
 
     def make_params(self, width, height, camera_position, pixel_to_ray, spp=PIXEL_SAMPLE_RATE,
                     bounce_limit=RAY_BOUNCE_LIMIT, t_min=RAY_INTERSECTION_T_MIN, seed=0x5EED, rect=None, flags=0,
-                    max_batch_paths=0):
+                    max_batch_paths=0, row_group=0, row_stride=0):
         p = _lib.RtRenderParams()
         p.width, p.height = width, height
         p.x0, p.y0, p.w, p.h = rect if rect is not None else (0, 0, width, height)
@@ -134,6 +134,7 @@ class DeviceScene:
         p.camera_position[:] = [float(x) for x in camera_position]
         p.pixel_to_ray[:] = [float(x) for x in pixel_to_ray]
         p.flags, p.max_batch_paths = flags, max_batch_paths
+        p.row_group, p.row_stride = row_group, row_stride
         return p
 
     def render(self, params):

@@ -9,11 +9,17 @@ depend on the number of ranks.
 import numpy as np
 
 
+def group_size(height, world_size, bands_per_rank=4):
+    """Rows per band: every band but the frame's last has exactly this many rows, which is what lets one
+    render call cover all of a rank's bands (rt_render_params.row_group / row_stride)."""
+    n = max(1, min(height, world_size * bands_per_rank))
+    return -(-height // n)
+
+
 def band_rows(height, world_size, bands_per_rank=4):
     """Row ranges [(y0, rows), ...] of all bands, in frame order.  Band b belongs to rank b % world_size."""
-    n = max(1, min(height, world_size * bands_per_rank))
-    edges = np.linspace(0, height, n + 1).round().astype(int)
-    return [(int(a), int(b - a)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+    g = group_size(height, world_size, bands_per_rank)
+    return [(y, min(g, height - y)) for y in range(0, height, g)]
 
 
 def rank_bands(height, world_size, rank, bands_per_rank=4):
@@ -39,6 +45,20 @@ def render_sharded(render_rect, width, height, rank, world_size, buffer, bands_p
             if isinstance(v, (int, float)):
                 total[k] = total.get(k, 0) + v
     return total
+
+
+def render_interleaved(render_rows, width, height, rank, world_size, buffer, bands_per_rank=4):
+    """Render all of this rank's bands with ONE call: render_rows(y0, rows, row_group, row_stride, out) renders
+    `rows` rows starting at image row y0 and skipping row_group * (row_stride - 1) rows after every row_group
+    rows, into `out` in that order -- the layout render_sharded produces with one call per band.  A bounce of
+    a deep scene costs every call a fixed latency tail, so one call per frame instead of one per band matters
+    at high rank counts.  Returns the call's stats."""
+    bands = rank_bands(height, world_size, rank, bands_per_rank)
+    rows = sum(r for _, _, r in bands)
+    if rows == 0:
+        return {}
+    g = group_size(height, world_size, bands_per_rank)
+    return render_rows(bands[0][1], rows, g, world_size, buffer[: rows * width * 3]) or {}
 
 
 def gather_frame(buffer, width, height, rank, world_size, bands_per_rank=4, dist=None):

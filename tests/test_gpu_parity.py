@@ -430,6 +430,36 @@ def test_dragon_scene_at_3840x2160_bands_of_eight_ranks(dragon900k, oracle_lib):
     assert sf["paths"] == w * h and np.isfinite(full).all()
 
 
+def test_interleaved_row_groups_equal_the_rows_of_the_full_frame(builtin):
+    """rt_render_params.row_group / row_stride: one call renders every row_stride-th group of rows (what one
+    GPU of several renders); the rows must be those of the frame rendered in one piece, for every rank, with a
+    partial last group, and the work must add up."""
+    from raytracing_amd import tiles
+    sc, ds = builtin
+    w, h = 200, 117
+    p2r = sc.pixel_to_ray_transform(w, h)
+    full, sf = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=3, seed=8))
+    for world, bpr in ((4, 3), (8, 8), (2, 1)):
+        g = tiles.group_size(h, world, bpr)
+        assembled = np.zeros_like(full)
+        segments = 0
+        for rank in range(world):
+            bands = tiles.rank_bands(h, world, rank, bpr)
+            rows = sum(r for _, _, r in bands)
+            if rows == 0:
+                continue
+            part, st = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=3, seed=8, rect=(0, bands[0][1], w, rows),
+                                                row_group=g, row_stride=world))
+            cursor = 0
+            for _, y0, r in bands:
+                assembled[y0:y0 + r] = part[cursor:cursor + r]
+                cursor += r
+            segments += st["segments"]
+        assert same_bits(assembled, full) and segments == sf["segments"]
+    with pytest.raises(_lib.RtError, match="outside"):
+        ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, rect=(0, 100, w, 17), row_group=16, row_stride=2))
+
+
 def test_multi_mesh_ten_million_triangles_twelve_bounces(oracle_lib):
     """Benchmark configuration 5: eleven instances of the 0.9 M-triangle surface (about 9.9 M triangles, 2 GB
     in HBM), low-roughness GGX, bounce limit 12.  Hits, a tile with every work counter, and a split frame."""

@@ -23,7 +23,9 @@ def test_bands_partition_the_frame(height, world, bpr):
     rows = [sum(r for _, _, r in tiles.rank_bands(height, world, k, bpr)) for k in range(world)]
     assert max(rows) == tiles.max_rank_rows(height, world, bpr)
     if height >= world * bpr:
-        assert max(rows) - min(rows) <= bpr          # balanced to within one row per band
+        assert max(rows) - min(rows) <= tiles.group_size(height, world, bpr)     # balanced to within one band
+    g = tiles.group_size(height, world, bpr)
+    assert all(r == g for _, r in bands[:-1]) and 0 < bands[-1][1] <= g           # fixed-size groups
 
 
 def _expected(width, height):
@@ -133,6 +135,28 @@ def test_broadcast_scene_render_gather_world_size_2():
         p.join(180)
         assert p.exitcode == 0
     assert result.get("ok") is True
+
+
+def test_interleaved_call_covers_the_same_rows_as_the_bands():
+    import torch
+    w, h, world, bpr = 12, 53, 4, 3
+    want = torch.from_numpy(_expected(w, h))
+    g = tiles.group_size(h, world, bpr)
+    for rank in range(world):
+        a = torch.zeros(tiles.max_rank_rows(h, world, bpr) * w * 3)
+        b = torch.zeros_like(a)
+
+        def render_rect(x0, y0, ww, hh, out):
+            out.copy_(want[y0:y0 + hh, x0:x0 + ww].reshape(-1))
+
+        def render_rows(y0, rows, row_group, row_stride, out):
+            ys = [y0 + r + (r // row_group) * row_group * (row_stride - 1) for r in range(rows)]     # the device's row map
+            assert row_group == g and row_stride == world and max(ys) < h
+            out.copy_(want[ys].reshape(-1))
+
+        tiles.render_sharded(render_rect, w, h, rank, world, a, bpr)
+        tiles.render_interleaved(render_rows, w, h, rank, world, b, bpr)
+        assert torch.equal(a, b)
 
 
 def test_single_rank_is_a_view():
