@@ -200,7 +200,10 @@ __device__ unsigned long long g_diag[16];
 #define DIAG_T(var) unsigned long long var = clock64()
 #define DIAG_ADD(slot, value) diag[slot] += (value)
 #define DIAG_LANES(iterSlot, laneSlot) do { diag[iterSlot] += 1; diag[laneSlot] += __popcll(__ballot(true)); } while (0)
+// once per wave, whichever lanes are here
+#define DIAG_WAVE(slot) do { if ((threadIdx.x & 63) == static_cast<unsigned>(__ffsll(static_cast<long long>(__ballot(true))) - 1)) atomicAdd(&g_diag[slot], 1ull); } while (0)
 #else
+#define DIAG_WAVE(slot)
 #define DIAG_T(var)
 #define DIAG_ADD(slot, value)
 #define DIAG_LANES(iterSlot, laneSlot)
@@ -320,6 +323,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
         while (cur != NONE && pend3 == NONE) {
             if (!COUNT) { if (__ballot(pend1 == NONE) == 0ull) break; }
             DIAG_LANES(6, 7);
+            DIAG_WAVE(5);
             float4 const q0 = S.nodes[2 * cur];
             float4 const q1 = S.nodes[2 * cur + 1];
             V3 const nlo = mk(q0.x, q0.y, q0.z), nhi = mk(q0.w, q1.x, q1.y);
@@ -330,8 +334,10 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             bool meets = (filterBits & 1) != 0;
             bool decided = (filterBits & 3) != 0;
             if (COUNT || !decided) {
+                DIAG_WAVE(14);
                 if (!decided && originInsideRule(filterBits, mu, o, nlo, nhi)) { meets = true; decided = true; }
                 if (COUNT || !decided) {
+                    DIAG_WAVE(15);
                     bool const exact = lineBox(o, d, nlo, nhi);
                     if (COUNT) {
                         if (!decided) c.boxFallbacks++;
@@ -477,7 +483,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     }
 #ifdef RT_DIAG
     if (lane == 0)
-        for (int k = 0; k < 16; ++k) if (diag[k]) atomicAdd(&g_diag[k], diag[k]);
+        for (int k = 0; k < 14; ++k) if (k != 5 && diag[k]) atomicAdd(&g_diag[k], diag[k]);
 #endif
 }
 

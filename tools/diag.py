@@ -18,12 +18,13 @@ _, st = ds.render(p)
 L.rt_diag_read(d, 0)
 v = list(d)
 tot = sum(v[0:5])
+v[5] -= 0
 print(f"{name} {spp} spp: {st['segments']} segments")
 for k, label in enumerate(["refill", "node walk", "leaf fetch", "triangle scan", "store"]):
     print(f"  {label:14s} {100.0 * v[k] / tot:5.1f} % of wave cycles")
 print(f"  walk loop: {v[6] / st['segments'] * 64:8.1f} wave iterations per 64 segments, {v[7] / max(v[6], 1):5.1f} lanes active")
 print(f"  tri pass 1: {v[8] / st['segments'] * 64:8.1f} wave iterations per 64 segments, {v[9] / max(v[8], 1):5.1f} lanes active")
 print(f"  tri pass 2: {v[10] / st['segments'] * 64:8.1f} wave iterations per 64 segments, {v[11] / max(v[10], 1):5.1f} lanes active")
-print(f"  tri pass 1b: {v[14] / st["segments"] * 64:8.1f} wave iterations per 64 segments, {v[15] / max(v[14], 1):5.1f} lanes active")
+print(f"  walk iterations in which some lane needs the origin-inside rule: {100.0 * v[14] / max(v[5], 1):5.1f} %, the exact box test: {100.0 * v[15] / max(v[5], 1):5.1f} % of {v[5] / st['segments'] * 64:.0f} wave iterations per 64 segments")
 print(f"  outer loop: {v[12] / st['segments'] * 64:8.1f} iterations per 64 segments, {v[13] / max(v[12], 1):5.1f} lanes hold a line")
 ds.close()
