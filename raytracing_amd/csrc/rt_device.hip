@@ -379,7 +379,11 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             uint32_t const here = cur;
             if (sp > 0) {                                                   // what follows this node
                 --sp;
-                cur = (!SPILL || sp < RT_LDS_STACK_DEPTH) ? stack[sp * RT_BLOCK] : spillStack[sp - RT_LDS_STACK_DEPTH];
+                // Always an LDS read (clamped index), overridden from scratch in the rare deep case: written as one
+                // conditional expression the compiler selects between the two ADDRESSES and emits a flat load,
+                // which goes through the texture path and drains both wait counters on every pop.
+                cur = stack[(SPILL ? min(sp, RT_LDS_STACK_DEPTH - 1) : sp) * RT_BLOCK];
+                if (SPILL && sp >= RT_LDS_STACK_DEPTH) cur = spillStack[sp - RT_LDS_STACK_DEPTH];
             }
             else cur = NONE;
             if (meets && index < 0) {
