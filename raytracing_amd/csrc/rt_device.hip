@@ -708,8 +708,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
     volatile uint32_t* const stage = stageAll + (threadIdx.x >> 6) * RT_STAGE;   // this wave's staging area
     uint32_t staged = 0;                                                          // wave-uniform
     // The loop bound is wave-uniform so that every lane reaches the ballot.
-    uint32_t const first = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
-    for (uint32_t base = first; base < n; base += stride) {
+    // A wave takes 256 consecutive entries (four steps of 64) before it moves on by the grid's stride, so that
+    // the runs it appends to the next queue come from neighbouring paths: the next bounce's waves then start
+    // on lines with nearby origins.
+    uint64_t const tileStride = static_cast<uint64_t>(stride) * 4u;
+    uint64_t const waveFirst = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~63u)) * 4u;
+    for (uint64_t step = 0;; ++step) {
+        uint64_t const base64 = (step >> 2) * tileStride + waveFirst + (step & 3u) * 64u;
+        if ((step & 3u) == 0u && base64 >= n) break;
+        if (base64 >= n) continue;
+        uint32_t const base = static_cast<uint32_t>(base64);
         uint32_t const i = base + lane;
         bool alive = false;
         uint32_t slot = 0;
