@@ -120,7 +120,8 @@ def roofline(workload, work, seg_per_launch, launch_ms, trace_share):
            "box_tests_per_segment": work["box_tests"] / work["segments"],
            "tris_tested_per_segment": work["tris_tested"] / work["segments"],
            "shaded_hits_per_segment": work["shaded_hits"] / work["segments"]}
-    pmc_file = os.path.join(ROOT, "profiles", f"roofline_{workload}.json")
+    # counter passes are per scene: the 4K workload shares the 1080p one's
+    pmc_file = os.path.join(ROOT, "profiles", f"roofline_{ {'dragon4k': 'dragon'}.get(workload, workload) }.json")
     traffic = None
     if os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
@@ -146,18 +147,21 @@ def roofline(workload, work, seg_per_launch, launch_ms, trace_share):
             a = d["l1_accesses_per_segment"] * seg_per_s
             miss1, hit2 = d["l1_miss_rate"], d["l2_hit_rate"]
             p1, p2, p3 = (peaks[f"gather16_lane_loads_per_s_{k}"] for k in ("l1", "l2", "mall"))
-            mix_peak = 1.0 / ((1.0 - miss1) / p1 + miss1 * hit2 / p2 + miss1 * (1.0 - hit2) / p3)
+            mix_rate = 1.0 / ((1.0 - miss1) / p1 + miss1 * hit2 / p2 + miss1 * (1.0 - hit2) / p3)
+            units = 256.0 / 8.0          # TA / TD units per XCD; GRBM_GUI_ACTIVE is summed over the 8 XCDs
             ceilings["texture_path"] = {
-                "achieved": a / 1e9, "peak": mix_peak / 1e9, "unit": "G lane-loads/s", "frac": a / mix_peak,
-                "peak_all_l1_hits": p1 / 1e9, "frac_of_all_l1_hits_peak": a / p1,
+                "achieved": a / 1e9, "peak": p1 / 1e9, "unit": "G lane-loads/s", "frac": a / p1,
                 "l1_miss_rate": miss1, "l2_hit_rate": hit2,
-                "td_busy_vs_pure_gather_kernel": (d.get("td_busy_per_gui_cycle", 0.0) / pmc["peak_gather_td_busy_per_gui_cycle"])
-                if pmc.get("peak_gather_td_busy_per_gui_cycle") else None,
-                "ta_busy_vs_pure_gather_kernel": (d.get("ta_busy_per_gui_cycle", 0.0) / pmc["peak_gather_ta_busy_per_gui_cycle"])
-                if pmc.get("peak_gather_ta_busy_per_gui_cycle") else None,
-                "note": "TCP_TOTAL_CACHE_ACCESSES (one per lane of a scattered 16-byte load) x segments/s against the rate of "
-                        "tools/ubench/peaks.hip's scattered 16-byte loads served from L1 / L2 / Infinity Cache, weighted by this "
-                        "kernel's measured L1 miss and L2 hit rates"}
+                "rate_of_calibration_loads_at_this_hit_mix": mix_rate / 1e9,
+                "td_busy": d.get("td_busy_per_gui_cycle", 0.0) / units, "ta_busy": d.get("ta_busy_per_gui_cycle", 0.0) / units,
+                "td_busy_of_calibration_kernel": pmc.get("peak_gather_td_busy_per_gui_cycle", 0.0) / units,
+                "ta_busy_of_calibration_kernel": pmc.get("peak_gather_ta_busy_per_gui_cycle", 0.0) / units,
+                "note": "TCP_TOTAL_CACHE_ACCESSES (one per lane of a scattered 16-byte load) x segments/s against the highest "
+                        "rate at which the chip serves scattered 16-byte loads: tools/ubench/peaks.hip, all 64 lanes active, "
+                        "4 loads in flight per lane, 16 KiB table (every load an L1 hit).  The same loads from a 1 MiB (L2) or "
+                        "64 MiB (Infinity Cache) table run 3.7x and 17x slower; weighted by this kernel's L1 miss and L2 hit "
+                        "rates that gives rate_of_calibration_loads_at_this_hit_mix, an estimate, not a bound.  td_busy / "
+                        "ta_busy: fraction of cycles the texture data / address units are busy, beside the calibration kernel's"}
     bound = max((k for k in ceilings if "frac" in ceilings[k]), key=lambda k: ceilings[k]["frac"], default=None)
     if bound is None:
         # no counter file for this workload: only the FP32 VALU fraction of the algorithmic flops can be stated
