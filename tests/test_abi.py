@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from raytracing_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
