@@ -98,7 +98,7 @@ def cpu_baseline(scene, width, height, bounce_limit, target_seconds=12.0):
             "segments_per_path": st["segments"] / st["paths"]}
 
 
-def roofline(workload, work, seg_per_launch, launch_ms, trace_share):
+def roofline(workload, work, seg_per_launch, launch_ms, trace_share, accel="bsp"):
     """Ceilings for k_trace, the dominant kernel.  Live inputs: segments per launch and the average launch
     duration (HIP events around every k_trace launch of the timed steps) and the work counters of an untimed
     counting step.  Counter inputs: per-segment HBM bytes, VALU instructions and cache accesses of k_trace from
@@ -106,22 +106,29 @@ def roofline(workload, work, seg_per_launch, launch_ms, trace_share):
     tools/roofline_passes.sh; a PMC pass cannot run inside the timed region), and the ceilings measured by the
     calibration kernels of tools/ubench/peaks.hip in the same passes."""
     seg_per_s = seg_per_launch / (launch_ms * 1e-3) if launch_ms > 0 else 0.0
-    bpt = (28.0 * work["box_tests"] + 52.0 * work["tris_tested"]) / work["segments"]
-    fps = (30.0 * work["box_tests"] + 38.0 * work["tris_tested"]) / work["segments"]
+    if accel == "bvh":
+        # a node visit reads 112 bytes (four child boxes and references) and costs about 20 flops per child box
+        bpt = (112.0 * work["inode_visits"] + 52.0 * work["tris_tested"]) / work["segments"]
+        fps = (20.0 * work["box_tests"] + 38.0 * work["tris_tested"]) / work["segments"]
+    else:
+        bpt = (28.0 * work["box_tests"] + 52.0 * work["tris_tested"]) / work["segments"]
+        fps = (30.0 * work["box_tests"] + 38.0 * work["tris_tested"]) / work["segments"]
     ceilings = {
         "algorithmic_zero_reuse": {
-            "note": "28 B per node box test + 52 B per triangle tested, every byte counted as if it came from HBM; "
+            "note": ("112 B per node visit" if accel == "bvh" else "28 B per node box test")
+                    + " + 52 B per triangle tested, every byte counted as if it came from HBM; "
                     "informational only: these bytes are served by L1/L2, so this is not a bound",
             "bytes_per_segment": bpt, "gbytes_per_s": bpt * seg_per_s / 1e9, "flops_per_segment": fps,
             "tflops": fps * seg_per_s / 1e12, "frac_of_fp32_valu_peak": fps * seg_per_s / 1e12 / FP32_VALU_PEAK_TFLOPS},
     }
-    out = {"kernel": "k_trace", "avg_launch_ms": launch_ms, "segments_per_launch": seg_per_launch,
+    out = {"kernel": "k_trace_bvh" if accel == "bvh" else "k_trace", "avg_launch_ms": launch_ms, "segments_per_launch": seg_per_launch,
            "segments_per_s_in_kernel": seg_per_s, "trace_share_of_kernel_time": trace_share,
            "box_tests_per_segment": work["box_tests"] / work["segments"],
            "tris_tested_per_segment": work["tris_tested"] / work["segments"],
+           "node_visits_per_segment": work["inode_visits"] / work["segments"],
            "shaded_hits_per_segment": work["shaded_hits"] / work["segments"]}
     # counter passes are per scene: the 4K workload shares the 1080p one's
-    pmc_file = os.path.join(ROOT, "profiles", f"roofline_{ {'dragon4k': 'dragon'}.get(workload, workload) }.json")
+    pmc_file = os.path.join(ROOT, "profiles", f"roofline_{ {'dragon4k': 'dragon'}.get(workload, workload) }{'_bvh' if accel == 'bvh' else ''}.json")
     traffic = None
     if os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
@@ -187,6 +194,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU when weak, per frame when strong)")
     ap.add_argument("--roulette", action="store_true", help="render with RT_FLAG_RUSSIAN_ROULETTE")
+    ap.add_argument("--accel", default="bsp", choices=["bsp", "bvh"],
+                    help="bsp: the reference's tree (results bit-identical to the reference's traversal); bvh: the "
+                         "alternative accelerator, a 4-wide bounding volume hierarchy (RT_FLAG_ACCEL_BVH)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -247,6 +257,12 @@ def main():
         ds = DeviceScene(rtd, device=local_rank)
         scene_bytes = 0
     cam_pos, p2r, triangles = header[0:3].astype(np.float32), header[3:12].astype(np.float32), int(header[12])
+    bvh_build_s = 0.0
+    if args.accel == "bvh":
+        # every rank builds the hierarchy from the scene bytes it holds (deterministic, so all ranks hold the same one)
+        t_bvh = time.perf_counter()
+        ds.build_bvh(4)
+        bvh_build_s = time.perf_counter() - t_bvh
     setup_s = time.perf_counter() - t_setup
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -256,7 +272,7 @@ def main():
     render_buf = torch.zeros(tiles.max_rank_rows(height, world, bands_per_rank) * width * 3, dtype=torch.float32, device="cuda")
     gatherer = tiles.FrameGatherer(width, height, rank, world, bands_per_rank, dist,
                                    buffer=(torch.zeros(render_buf.numel()) if share_gpu and world > 1 else render_buf))
-    extra = _lib.RT_FLAG_RUSSIAN_ROULETTE if args.roulette else 0
+    extra = (_lib.RT_FLAG_RUSSIAN_ROULETTE if args.roulette else 0) | (_lib.RT_FLAG_ACCEL_BVH if args.accel == "bvh" else 0)
 
     def step(seed, flags, spp_step):
         def render_rows(y0, rows, row_group, row_stride, out):
@@ -310,12 +326,14 @@ def main():
             "config": {"workload": description, "name": args.workload, "width": width, "height": height,
                        "spp_total": spp, "spp_per_gpu": spp1, "bounce_limit": bounce_limit,
                        "russian_roulette": bool(args.roulette), "triangles": triangles, "tree_depth": ds.depth,
+                       "accelerator": "reference BSP tree" if args.accel == "bsp" else "4-wide bounding volume hierarchy (not the reference's accelerator)",
+                       "bvh_build_s": bvh_build_s,
                        "parallelism": (f"pixel bands over {world} GPUs, scene broadcast once from rank 0 "
                                        f"({scene_bytes / 1e6:.1f} MB), bands gathered to rank 0 every frame") if world > 1
                        else "one GPU, one rectangle",
                        "scene_setup_s": setup_s, "segments_per_step": seg / args.steps, "image_finite": finite},
             "roofline": roofline(args.workload, work, seg_rank / max(launches, 1), trace_ms / max(launches, 1),
-                                 trace_ms / max(trace_ms + shade_ms, 1e-9)),
+                                 trace_ms / max(trace_ms + shade_ms, 1e-9), args.accel),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, width, height, bounce_limit)

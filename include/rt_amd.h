@@ -82,6 +82,18 @@ typedef struct {
 
 typedef struct rt_scene rt_scene;
 
+/* One node of the alternative accelerator, a 4-wide bounding volume hierarchy (no counterpart in the
+ * reference, whose only accelerator is BSPTree, src/bsp.hpp:35-48).  128 bytes: the boxes of up to four
+ * children as a structure of arrays, then the child references.  child[k] == 0xFFFFFFFF: no child;
+ * bit 31 set: a leaf, triangles [first, first+count) of the hierarchy's triangle order with
+ * first = bits 0-27 and count-1 = bits 28-30; otherwise the number of an interior node, always larger
+ * than the node's own number (node 0 is the root). */
+typedef struct {
+    float lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4];
+    uint32_t child[4];
+    uint32_t pad_[4];
+} rt_bvh4_node;
+
 /* LineMeshIntersection (src/bsp.hpp:23-29).  mesh == 0xFFFFFFFF marks "no intersection"
  * (std::nullopt in the reference). */
 typedef struct {
@@ -97,6 +109,16 @@ typedef struct {
  * p = min(1, largest throughput component), drawn from the bounce's own Philox block, and its throughput
  * is divided by p.  The converged image is unchanged; fewer long paths are traced. */
 #define RT_FLAG_RUSSIAN_ROULETTE 4u
+/* Answer the path loop's nearest-intersection queries (src/render.hpp:104) from the bounding volume
+ * hierarchy attached with rt_scene_attach_bvh4 instead of the BSP tree.  Same triangle test, bit for bit
+ * (src/geometry.hpp:99-132); the nearest accepted triangle over the whole scene is returned, without the
+ * BSP leaf's in-box rule (src/bsp.hpp:82-87), so the two accelerators can differ on rays that graze a
+ * triangle edge-on or hit exactly on a leaf boundary.  The converged image is unchanged. */
+#define RT_FLAG_ACCEL_BVH 8u
+/* For the front_only argument of rt_intersect / rt_intersect_device: bit 0 = front faces only
+ * (Surfaces::FRONT_ONLY, src/geometry.hpp:95-97), bit 1 = use the attached bounding volume hierarchy. */
+#define RT_INTERSECT_FRONT_ONLY 1
+#define RT_INTERSECT_BVH 2
 
 /* RenderData (src/render.hpp:38-44) + the compile-time constants of src/render.hpp:47-49 made
  * run-time, + a tile rectangle for multi-GPU sharding. */
@@ -145,6 +167,15 @@ void rt_scene_destroy(rt_scene* scene);
 int rt_scene_serialize(const rt_scene_desc* desc, void* blob, uint64_t* size);
 int rt_scene_desc_from_blob(const void* blob, uint64_t size, rt_scene_desc* out_desc);
 int rt_scene_create_from_blob(const void* blob, uint64_t size, int device, rt_scene** out);
+/* Attach a 4-wide bounding volume hierarchy over desc->pretris (which must be non-null) to an uploaded
+ * scene: tri_order[k] is the index into desc->pretris of the hierarchy's k-th triangle (a permutation of
+ * 0..pretri_count-1).  The nodes are validated (child numbers ascending, leaf ranges inside the triangle
+ * order, at most 64 deferred children on any descent) before anything is uploaded.
+ * rt_scene_build_bvh4 builds one with rt_bvh4_build (rt_host.h) and attaches it; max_leaf_tris 1..8,
+ * threads as for rt_bsp_build. */
+int rt_scene_attach_bvh4(rt_scene* scene, const rt_scene_desc* desc, const rt_bvh4_node* nodes, uint32_t node_count,
+                         const uint32_t* tri_order);
+int rt_scene_build_bvh4(rt_scene* scene, const rt_scene_desc* desc, uint32_t max_leaf_tris, int threads);
 /* Bytes of HBM held by the scene, and the depth of its tree. */
 int rt_scene_info(const rt_scene* scene, uint64_t* device_bytes, uint32_t* node_count, uint32_t* leaf_tri_count,
                   uint32_t* depth);

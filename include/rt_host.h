@@ -101,6 +101,20 @@ void rt_bsp_counts(const rt_bsp* bsp, uint32_t counts[5]);
 void rt_bsp_view(const rt_bsp* bsp, float root_box[6], int32_t* root_index, const rt_inode** inodes,
                  const uint32_t** leaf_first_ref, const rt_tri_ref** leaf_refs);
 
+/* Builder of the alternative accelerator (rt_bvh4_node, rt_amd.h): binned surface-area-heuristic splits
+ * down to leaves of at most max_leaf_tris (1..8) triangles, two binary levels folded into each 4-wide
+ * node, node boxes padded by 2^-18 of the largest coordinate.  pretris: 12 floats per triangle as in
+ * rt_scene_desc.  The result does not depend on `threads` (<= 0: OMP_NUM_THREADS or up to 16 hardware
+ * threads).  No counterpart in the reference. */
+typedef struct rt_bvh4 rt_bvh4;
+int rt_bvh4_build(const float* pretris, uint32_t pretri_count, uint32_t max_leaf_tris, int threads, rt_bvh4** out);
+void rt_bvh4_destroy(rt_bvh4* bvh);
+/* node_count, triangle_count, depth (levels of 4-wide nodes), stack_need (largest number of deferred
+ * children on any descent), leaf_count, largest leaf. */
+void rt_bvh4_counts(const rt_bvh4* bvh, uint32_t counts[6]);
+/* Views valid until rt_bvh4_destroy; tri_order[k] = index into pretris of the hierarchy's k-th triangle. */
+void rt_bvh4_view(const rt_bvh4* bvh, const rt_bvh4_node** nodes, const uint32_t** tri_order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ class RenderParams(ctypes.Structure):
 
 
 FLAG_RUSSIAN_ROULETTE = 4
+FLAG_ACCEL_BVH = 8
 
 
 class Stats(ctypes.Structure):
@@ -227,15 +228,40 @@ class Scene:
         self.L._f("get_bsp")(self.h, *[_p(v) for v in d.values()])
         return d
 
-    def intersect(self, origins, directions, t_min=1e-3, front_only=True):
+    def intersect(self, origins, directions, t_min=1e-3, front_only=True, use_bvh=False):
         o = np.ascontiguousarray(origins, np.float32)
         d = np.ascontiguousarray(directions, np.float32)
         n = o.shape[0]
         f = np.zeros((n, 6), np.float32)
         ids = np.zeros((n, 2), np.uint32)
-        self.L._f("intersect")(self.h, _p(o), _p(d), _c.c_size_t(n), _c.c_float(t_min), _c.c_int(int(front_only)),
-                               _p(f), _p(ids))
+        assert not (use_bvh and self.L.is_ref)
+        self.L._f("intersect")(self.h, _p(o), _p(d), _c.c_size_t(n), _c.c_float(t_min),
+                               _c.c_int(int(bool(front_only)) | (2 if use_bvh else 0)), _p(f), _p(ids))
         return f, ids
+
+    def intersect_brute(self, origins, directions, t_min=1e-3, front_only=True):
+        """C oracle only: nearest accepted triangle by scanning all triangles (no accelerator)."""
+        assert not self.L.is_ref
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(directions, np.float32)
+        n = o.shape[0]
+        f = np.zeros((n, 6), np.float32)
+        ids = np.zeros((n, 2), np.uint32)
+        self.L.lib.orc_intersect_brute(self.h, _p(o), _p(d), _c.c_size_t(n), _c.c_float(t_min),
+                                       _c.c_int(int(bool(front_only))), _p(f), _p(ids))
+        return f, ids
+
+    def set_bvh4(self, nodes, tri_order):
+        """C oracle only: hand over the product's bounding volume hierarchy (128-byte nodes, triangle order) for the
+        restated traversal (intersect(use_bvh=True), render_params(flags=FLAG_ACCEL_BVH))."""
+        assert not self.L.is_ref
+        nodes = np.ascontiguousarray(nodes)
+        assert nodes.dtype.itemsize == 128
+        order = np.ascontiguousarray(tri_order, np.uint32)
+        f = self.L.lib.orc_scene_set_bvh4
+        f.restype = _c.c_int
+        rc = f(self.h, _p(nodes), _c.c_uint32(len(nodes)), _p(order), _c.c_uint32(len(order)))
+        assert rc == 0, "orc_scene_set_bvh4: size mismatch"
 
     def camera_rays(self, sample_xy):
         xy = np.ascontiguousarray(sample_xy, np.float32)

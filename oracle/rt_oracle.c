@@ -234,6 +234,9 @@ struct orc_scene {
     tri_block* blocks; uint32_t blockCount;
     int simdLeaves;                /* leaf test: 0 = one triangle at a time, 1 = AVX2, 8 triangles per step */
     int buildFailed;
+    /* the product's alternative accelerator (orc_scene_set_bvh4); not part of the reference */
+    float* bvhNodes; uint32_t bvhNodeCount;        /* 32 words per node */
+    pretri* bvhTris; uint32_t* bvhMesh; uint32_t* bvhTri; uint32_t* bvhGlobal; uint32_t bvhTriCount;
 };
 
 /* src/material.hpp:32-45 */
@@ -546,7 +549,8 @@ void orc_scene_destroy(orc_scene* s) {
     if (!s) return;
     free(s->baseTris); free(s->meshTriRanges); free(s->modelMeshes); free(s->positions); free(s->normals);
     free(s->vertexRanges); free(s->pretris); free(s->triRanges); free(s->modelMaterials);
-    free(s->inodes); free(s->leaves); free(s->refMesh); free(s->refTri); free(s->refTris); free(s->blocks); free(s);
+    free(s->inodes); free(s->leaves); free(s->refMesh); free(s->refTri); free(s->refTris); free(s->blocks);
+    free(s->bvhNodes); free(s->bvhTris); free(s->bvhMesh); free(s->bvhTri); free(s->bvhGlobal); free(s);
 }
 
 void orc_scene_counts(const orc_scene* s, uint32_t* c) {
@@ -728,9 +732,143 @@ static int visit_node(const traverser* tr, const bsp_node* node, hit_rec* out) {
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* The product's alternative accelerator.  NOT in the reference: a restatement of the library's */
+/* own 4-wide bounding-volume-hierarchy traversal (rt_device.hip, traceStreamBvh), so that the  */
+/* GPU traversal can be checked bit for bit.  Only the triangle test inside it is the           */
+/* reference's (line_tri above, src/geometry.hpp:99-132).                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Node layout (rt_bvh4_node, 32 words): lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4] pad[4]. */
+int orc_scene_set_bvh4(orc_scene* s, const float* nodes, uint32_t nodeCount, const uint32_t* triOrder, uint32_t triCount) {
+    if (!s || !nodes || nodeCount == 0 || triCount != s->triCount) return -1;
+    free(s->bvhNodes); free(s->bvhTris); free(s->bvhMesh); free(s->bvhTri); free(s->bvhGlobal);
+    s->bvhGlobal = (uint32_t*)malloc(4 * (size_t)(triCount ? triCount : 1));
+    s->bvhNodes = (float*)malloc((size_t)nodeCount * 128);
+    s->bvhTris = (pretri*)malloc(sizeof(pretri) * (size_t)(triCount ? triCount : 1));
+    s->bvhMesh = (uint32_t*)malloc(4 * (size_t)(triCount ? triCount : 1));
+    s->bvhTri = (uint32_t*)malloc(4 * (size_t)(triCount ? triCount : 1));
+    if (!s->bvhNodes || !s->bvhTris || !s->bvhMesh || !s->bvhTri || !s->bvhGlobal) return -1;
+    memcpy(s->bvhNodes, nodes, (size_t)nodeCount * 128);
+    s->bvhNodeCount = nodeCount;
+    s->bvhTriCount = triCount;
+    for (uint32_t k = 0; k < triCount; ++k) {
+        uint32_t g = triOrder[k];
+        if (g >= triCount) return -1;
+        uint32_t m = 0;
+        while (m + 1 < s->modelCount && g >= s->triRanges[2 * (m + 1)]) ++m;
+        s->bvhTris[k] = s->pretris[g];
+        s->bvhMesh[k] = m;
+        s->bvhTri[k] = g - s->triRanges[2 * m];
+        s->bvhGlobal[k] = g;
+    }
+    return 0;
+}
+
+/* Entry parameter of the line into child k's box, +inf when it misses within [lower, upper]. */
+static inline float bvh_child_entry(v3 o, v3 r, const float* n, int k, float lower, float upper) {
+    float ax = (n[k] - o.x) * r.x, bx = (n[12 + k] - o.x) * r.x;
+    float ay = (n[4 + k] - o.y) * r.y, by = (n[16 + k] - o.y) * r.y;
+    float az = (n[8 + k] - o.z) * r.z, bz = (n[20 + k] - o.z) * r.z;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), lower));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), upper));
+    return tn <= tf * (1.0f + 0x1p-22f) ? tn : INFINITY;
+}
+
+static int bvh_nearest_hit(const orc_scene* s, v3 o, v3 d, float tMin, int frontOnly, hit_rec* out, orc_stats* st) {
+    const uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t stack[256];
+    int sp = 0, found = 0;
+    uint32_t cur = 0, bestSlot = 0;
+    v3 r = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float lower = fminf(tMin, 0.0f);
+    float bestT = INFINITY, bestU = 0.0f, bestV = 0.0f;
+    while (cur != NONE) {
+        if (!(cur & 0x80000000u)) {
+            const float* n = s->bvhNodes + 32 * (size_t)cur;
+            uint32_t child[4];
+            memcpy(child, n + 24, 16);
+            float t[4];
+            int nHit = 0;
+            if (st) st->inodeVisits++;
+            for (int k = 0; k < 4; ++k) {
+                t[k] = bvh_child_entry(o, r, n, k, lower, bestT);
+                if (child[k] == NONE) t[k] = INFINITY;
+                else if (st) st->boxTests++;
+                if (t[k] < INFINITY) ++nHit;
+            }
+            if (nHit == 0) { cur = sp > 0 ? stack[--sp] : NONE; continue; }
+            /* position in ascending (entry, slot) order */
+            int pos[4];
+            for (int k = 0; k < 4; ++k) {
+                pos[k] = 0;
+                for (int j = 0; j < 4; ++j)
+                    if (j != k && (t[j] < t[k] || (t[j] == t[k] && j < k))) ++pos[k];
+            }
+            for (int k = 0; k < 4; ++k) {
+                if (pos[k] == 0) cur = child[k];
+                else if (pos[k] < nHit) stack[sp + nHit - 1 - pos[k]] = child[k];
+            }
+            sp += nHit - 1;
+        }
+        else {
+            uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
+            if (st) { st->leafVisits++; st->trisTested += count; }
+            for (uint32_t j = 0; j < count; ++j) {
+                float t, u, v;
+                if (!line_tri(&s->bvhTris[first + j], o, d, frontOnly, &t, &u, &v) || !(t >= tMin)) continue;
+                /* equal t: the lower scene-wide triangle index wins */
+                if (t < bestT || (t == bestT && found && s->bvhGlobal[first + j] < s->bvhGlobal[bestSlot])) {
+                    bestT = t; bestU = u; bestV = v; bestSlot = first + j; found = 1;
+                }
+            }
+            cur = sp > 0 ? stack[--sp] : NONE;
+        }
+    }
+    if (found) {
+        out->t = bestT; out->u = bestU; out->v = bestV;
+        out->point = V(o.x + bestT * d.x, o.y + bestT * d.y, o.z + bestT * d.z);
+        out->mesh = s->bvhMesh[bestSlot]; out->tri = s->bvhTri[bestSlot];
+    }
+    return found;
+}
+
+/* frontOnly: bit 0 = Surfaces::FRONT_ONLY, bit 1 = answer from the product's bounding volume hierarchy */
 static int nearest_hit(const orc_scene* s, v3 o, v3 d, float tMin, int frontOnly, hit_rec* out, orc_stats* st) {
-    traverser tr = {s, o, d, tMin, frontOnly, st};
+    if (frontOnly & 2) return s->bvhNodes ? bvh_nearest_hit(s, o, d, tMin, frontOnly & 1, out, st) : 0;
+    traverser tr = {s, o, d, tMin, frontOnly & 1, st};
     return visit_node(&tr, &s->root, out);
+}
+
+/* Nearest triangle the reference's test accepts (src/geometry.hpp:99-132) with t >= tMin, by scanning every
+ * triangle of the scene; among equal t the lowest scene-wide index.  No accelerator at all: the yardstick for
+ * the alternative accelerator, whose answer must be this one. */
+void orc_intersect_brute(const orc_scene* s, const float* origins, const float* directions, size_t n, float tMin,
+                         int frontOnly, float* outFloats, uint32_t* outIds) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long long i = 0; i < (long long)n; ++i) {
+        v3 o = ld3(origins + 3 * i), d = ld3(directions + 3 * i);
+        float bestT = INFINITY, bestU = 0.0f, bestV = 0.0f;
+        uint32_t best = 0xFFFFFFFFu;
+        for (uint32_t g = 0; g < s->triCount; ++g) {
+            float t, u, v;
+            if (line_tri(&s->pretris[g], o, d, frontOnly & 1, &t, &u, &v) && t >= tMin && t < bestT) {
+                bestT = t; bestU = u; bestV = v; best = g;
+            }
+        }
+        float* f = outFloats + 6 * i;
+        if (best != 0xFFFFFFFFu) {
+            uint32_t m = 0;
+            while (m + 1 < s->modelCount && best >= s->triRanges[2 * (m + 1)]) ++m;
+            f[0] = bestT; f[1] = bestU; f[2] = bestV;
+            st3(f + 3, V(o.x + bestT * d.x, o.y + bestT * d.y, o.z + bestT * d.z));
+            outIds[2 * i] = m; outIds[2 * i + 1] = best - s->triRanges[2 * m];
+        }
+        else {
+            for (int k = 0; k < 6; ++k) f[k] = 0.0f;
+            outIds[2 * i] = outIds[2 * i + 1] = 0xFFFFFFFFu;
+        }
+    }
 }
 
 void orc_intersect(const orc_scene* s, const float* origins, const float* directions, size_t n, float tMin,
@@ -877,13 +1015,15 @@ static inline void sampler_pair(sampler* sm, uint32_t dim, float* u0, float* u1r
  * after the loop; the per-lane arithmetic is independent, so evaluating bounce b's weight when it is
  * produced and keeping a running throughput gives the same bits:
  *   lightWeights[k] = w[k-1] * lightWeights[k-1], outgoing = fma(lightWeights[k], emission[k], outgoing). */
-static v3 ray_trace(const orc_scene* s, v3 o, v3 d, sampler* sm, uint32_t bounceLimit, float tMin, int roulette, orc_stats* st) {
+static v3 ray_trace(const orc_scene* s, v3 o, v3 d, sampler* sm, uint32_t bounceLimit, float tMin, uint32_t flags, orc_stats* st) {
+    int const roulette = (flags & ORC_FLAG_RUSSIAN_ROULETTE) != 0;
+    int const mode = 1 | ((flags & ORC_FLAG_ACCEL_BVH) ? 2 : 0);
     v3 throughput = V(1.0f, 1.0f, 1.0f), light = V(0.0f, 0.0f, 0.0f);
     uint32_t bounce = 0;
     for (;;) {
         hit_rec h;
         if (st) st->segments++;
-        if (!nearest_hit(s, o, d, tMin, 1, &h, st)) break;
+        if (!nearest_hit(s, o, d, tMin, mode, &h, st)) break;
         const premat* m = &s->modelMaterials[h.mesh];
         light = V(fmaf(throughput.x, m->emission.x, light.x), fmaf(throughput.y, m->emission.y, light.y),
                   fmaf(throughput.z, m->emission.z, light.z));
@@ -967,7 +1107,7 @@ void orc_path_radiance_device_mode(const orc_scene* s, const orc_render_params* 
     float sx = (float)pixelX + jx, sy = (float)pixelY + jy;
     v3 d = camera_ray(p->pixelToRay, sx, sy);
     if (st) st->paths++;
-    st3(rgb, ray_trace(s, ld3(p->cameraPosition), d, &sm, p->bounceLimit, p->tMin, (p->flags & ORC_FLAG_RUSSIAN_ROULETTE) != 0, st));
+    st3(rgb, ray_trace(s, ld3(p->cameraPosition), d, &sm, p->bounceLimit, p->tMin, p->flags, st));
 }
 
 void orc_render_device_mode(const orc_scene* s, const orc_render_params* p, float* image, orc_stats* stats, int threads) {

@@ -71,6 +71,11 @@ void orc_scene_destroy(orc_scene*);
 /* Leaf test: 0 (default) one triangle at a time; 1 the reference's own shape, 8 triangles per AVX2/FMA step
  * (src/geometry.hpp:117-132).  Same bits either way; the second is what the CPU baseline times. */
 void orc_scene_set_simd_leaves(orc_scene*, int enable);
+/* The product's alternative accelerator (not in the reference): a 4-wide bounding volume hierarchy as the
+ * library's builder lays it out (32 words per node) and the order of the scene's triangles in its leaves.
+ * orc_intersect with bit 1 of frontOnly set, and device-mode rendering with ORC_FLAG_ACCEL_BVH, then restate
+ * the library's traversal of it.  Returns 0, or -1 on a size mismatch. */
+int orc_scene_set_bvh4(orc_scene*, const float* nodes, uint32_t nodeCount, const uint32_t* triOrder, uint32_t triCount);
 void orc_get_camera(const orc_scene*, float* cameraPosition, float* pixelToRay);
 
 /* counts: [0] models [1] instantiated vertices [2] preprocessed tris [3] inodes [4] leaves
@@ -87,6 +92,10 @@ void orc_get_bsp(const orc_scene*, float* rootBox, int32_t* rootIndex, float* in
 void orc_intersect(const orc_scene*, const float* origins, const float* directions, size_t n, float tMin,
                    int frontOnly, float* outFloats, uint32_t* outIds);
 /* src/render.hpp:227 */
+/* The same query answered without any accelerator: every triangle is tested (src/geometry.hpp:99-132), the
+ * nearest accepted one with t >= tMin wins, among equal t the lowest scene-wide index. */
+void orc_intersect_brute(const orc_scene*, const float* origins, const float* directions, size_t n, float tMin,
+                         int frontOnly, float* outFloats, uint32_t* outIds);
 void orc_camera_rays(const orc_scene*, const float* sampleXY, size_t n, float* directions);
 
 /* ---- reference-mode shading (FastRNG + libm sinf/cosf), bit-comparable with the reference ---- */
@@ -113,6 +122,8 @@ typedef struct {
 /* Russian roulette from the third bounce on (an estimator extension of the product, not in the reference):
  * survive with probability min(1, largest throughput component), throughput divided by it. */
 #define ORC_FLAG_RUSSIAN_ROULETTE 4u
+/* Nearest-hit queries answered from the product's alternative accelerator (orc_scene_set_bvh4). */
+#define ORC_FLAG_ACCEL_BVH 8u
 
 typedef struct {
     uint64_t segments;               /* closest-hit queries issued by the path loop (src/render.hpp:104) */

@@ -28,7 +28,12 @@ INODE_DTYPE = np.dtype([("neg_box", np.float32, 6), ("neg_index", np.int32), ("p
 TRI_REF_DTYPE = np.dtype([("mesh", np.uint32), ("tri", np.uint32)])
 HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("point", np.float32, 3),
                       ("mesh", np.uint32), ("tri", np.uint32)])
+# rt_bvh4_node: one 128-byte node of the alternative accelerator (include/rt_amd.h)
+BVH4_NODE_DTYPE = np.dtype([("lo_x", np.float32, 4), ("lo_y", np.float32, 4), ("lo_z", np.float32, 4),
+                            ("hi_x", np.float32, 4), ("hi_y", np.float32, 4), ("hi_z", np.float32, 4),
+                            ("child", np.uint32, 4), ("pad_", np.uint32, 4)])
 assert INODE_DTYPE.itemsize == 60 and ctypes.sizeof(RtInode) == 60 and HIT_DTYPE.itemsize == 32
+assert BVH4_NODE_DTYPE.itemsize == 128
 
 
 class RtSceneDesc(ctypes.Structure):
@@ -62,15 +67,18 @@ class RtStats(ctypes.Structure):
 RT_FLAG_COUNT_WORK = 1
 RT_FLAG_PROFILE_KERNELS = 2
 RT_FLAG_RUSSIAN_ROULETTE = 4
+RT_FLAG_ACCEL_BVH = 8
+RT_INTERSECT_FRONT_ONLY = 1
+RT_INTERSECT_BVH = 2
 RT_STATIC_MAX_PIXELS = 262144
 
 # Every symbol declared by include/rt_amd.h and include/rt_host.h.
-DEVICE_SYMBOLS = ["rt_scene_create", "rt_scene_serialize", "rt_scene_desc_from_blob", "rt_scene_create_from_blob", "rt_scene_destroy", "rt_scene_info", "rt_intersect", "rt_intersect_device",
+DEVICE_SYMBOLS = ["rt_scene_create", "rt_scene_serialize", "rt_scene_desc_from_blob", "rt_scene_create_from_blob", "rt_scene_destroy", "rt_scene_attach_bvh4", "rt_scene_build_bvh4", "rt_scene_info", "rt_intersect", "rt_intersect_device",
                   "rt_render", "rt_render_device", "rt_render_device_static", "rt_postprocess", "rt_postprocess_device", "rt_selftest_math",
                   "rt_last_error", "rt_abi_version"]
 HOST_SYMBOLS = ["rt_preprocess_material", "rt_quat_from_euler", "rt_camera_basis", "rt_pixel_to_ray_transform",
                 "rt_instantiate_meshes", "rt_preprocess_tris", "rt_instantiate_meshes_device", "rt_preprocess_tris_device", "rt_scene_bounding_box", "rt_line_intersects_box",
-                "rt_tri_intersects_box", "rt_srgb_to_linear", "rt_linear_to_srgb", "rt_bsp_build", "rt_bsp_destroy", "rt_bsp_counts", "rt_bsp_view", "rt_write_ppm",
+                "rt_tri_intersects_box", "rt_srgb_to_linear", "rt_linear_to_srgb", "rt_bsp_build", "rt_bsp_destroy", "rt_bsp_counts", "rt_bsp_view", "rt_bvh4_build", "rt_bvh4_destroy", "rt_bvh4_counts", "rt_bvh4_view", "rt_write_ppm",
                 "rt_mesh_load", "rt_mesh_counts", "rt_mesh_view", "rt_mesh_destroy", "rt_mesh_last_error"]
 
 _lib = None

@@ -7,6 +7,7 @@
 // operations are written explicitly with __fmaf_rn.  Division and square root use HIP's default
 // correctly rounded forms.
 #include "rt_amd.h"
+#include "rt_host.h"
 
 #include <hip/hip_runtime.h>
 
@@ -491,6 +492,192 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
 #endif
 }
 
+// ---- alternative accelerator: 4-wide bounding volume hierarchy ----------------------------------------
+// Node record (rt_bvh4_node, 128 bytes = eight float4): child boxes as a structure of arrays
+//   {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]} {child[4]} {unused}
+// child: 0xFFFFFFFF none; bit 31: leaf, first triangle in bits 0-27, count-1 in bits 28-30; else a node number.
+// Triangle records and ids have the layout of the BSP leaves' (48 and 16 bytes), one per triangle.
+//
+// Entry parameter of the line into one child box, or +inf when it misses the box within [lower, upper]:
+// slab crossing parameters (plane - origin) * RN(1/direction), the far end widened by one part in 2^22 so
+// that rounding cannot lose a box the exact line touches (the boxes are padded as well).  Written with
+// fminf/fmaxf, which return the other operand when one is NaN (0 * inf of an axis-parallel line on a
+// box plane), so such an axis does not constrain the interval.
+__device__ __forceinline__ float childEntry(V3 o, V3 r, float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                            float lower, float upper) {
+    float const ax = (lox - o.x) * r.x, bx = (hix - o.x) * r.x;
+    float const ay = (loy - o.y) * r.y, by = (hiy - o.y) * r.y;
+    float const az = (loz - o.z) * r.z, bz = (hiz - o.z) * r.z;
+    float const tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), lower));
+    float const tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), upper));
+    return tn <= tf * (1.0f + 0x1p-22f) ? tn : INFINITY;
+}
+
+// Nearest accepted triangle over the whole scene for a stream of n lines, one lane per line: the query of
+// src/bsp.hpp:50-51 answered from the hierarchy.  Each triangle is tested with the reference's arithmetic
+// (src/geometry.hpp:99-132) and accepted when t >= tMin and t < the best so far; among equal t the triangle
+// with the lowest scene-wide index wins (the order of a BSP leaf's scan, src/bsp.hpp:73-97), so the answer
+// does not depend on the visiting order.  Children are visited nearest entry first (ties: lower slot first), the
+// others are deferred on the per-lane stack farthest first; a child whose entry lies beyond the best hit
+// is not visited.  Same persistent shape as traceStream: lanes walk nodes until each stands on a leaf (or
+// has finished), then the wave tests leaf triangles together; finished lanes take the next line.
+template <bool FRONT_ONLY, bool COUNT, bool SPILL, class Load, class Store>
+__device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, uint32_t* __restrict__ nextLine, float tMin,
+                                               Counters& c, Load load, Store store) {
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t const lane = threadIdx.x & 63u;
+    unsigned long long const below = (1ull << lane) - 1ull;
+    __shared__ uint32_t ldsStackBvh[RT_LDS_STACK_DEPTH * RT_BLOCK];
+    uint32_t spillStack[SPILL ? RT_STACK_MAX - RT_LDS_STACK_DEPTH : 1];
+    uint32_t* const stack = ldsStackBvh + threadIdx.x;
+    uint32_t const waves = gridDim.x * (RT_BLOCK / 64u);
+    uint32_t const xcdBlocks = gridDim.x / 8u;
+    uint32_t const vblock = (gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * xcdBlocks + blockIdx.x / 8u : blockIdx.x;
+    uint32_t const waveId = vblock * (RT_BLOCK / 64u) + (threadIdx.x >> 6);
+    uint32_t const staticRounds = static_cast<uint32_t>((static_cast<uint64_t>(n) * 3u / 4u) / (static_cast<uint64_t>(waves) * RT_FETCH_CHUNK));
+    uint32_t const staticLines = staticRounds * waves * RT_FETCH_CHUNK;
+    uint32_t staticRound = 0;
+    uint32_t chunkNext = 0, chunkEnd = 0;
+    bool drained = false;
+    bool active = false;
+    uint32_t line = 0, cur = NONE;
+    int sp = 0;
+    V3 o = mk(0.0f, 0.0f, 0.0f), d = o, r = o;
+    float const lower = fminf(tMin, 0.0f);
+    HitRec best;
+    best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
+
+    for (;;) {
+        // ---- refill idle lanes (as in traceStream) ------------------------------------------------
+        unsigned long long idle = __ballot(!active);
+        while (idle != 0ull && !drained) {
+            if (chunkNext == chunkEnd) {
+                uint32_t base = 0;
+                if (staticRound < staticRounds) {
+                    base = (staticRound * waves + waveId) * RT_FETCH_CHUNK;
+                    ++staticRound;
+                }
+                else {
+                    if (lane == 0) base = atomicAdd(nextLine, RT_FETCH_CHUNK);
+                    base = staticLines + __builtin_amdgcn_readfirstlane(base);
+                }
+                if (base >= n) { drained = true; break; }
+                chunkNext = base;
+                chunkEnd = min(base + RT_FETCH_CHUNK, n);
+            }
+            uint32_t const avail = chunkEnd - chunkNext;
+            uint32_t const rank = static_cast<uint32_t>(__popcll(idle & below));
+            if (!active && rank < avail) {
+                line = chunkNext + rank;
+                load(line, o, d);
+                r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                sp = 0; cur = 0;
+                best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
+                active = true;
+            }
+            chunkNext += min(static_cast<uint32_t>(__popcll(idle)), avail);
+            idle = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) break;
+        if (!active) continue;
+
+        // ---- phase 1: interior nodes until the lane stands on a leaf or has nothing left ------------
+        while ((cur & 0x80000000u) == 0u) {
+            float4 const* np = S.nodes + 8 * static_cast<size_t>(cur);
+            float4 const lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+            float4 const cf = np[6];
+            uint32_t const c0 = __float_as_uint(cf.x), c1 = __float_as_uint(cf.y), c2 = __float_as_uint(cf.z),
+                           c3 = __float_as_uint(cf.w);
+            if (COUNT) { c.inodeVisits++; c.boxTests += (c0 != NONE) + (c1 != NONE) + (c2 != NONE) + (c3 != NONE); }
+            float t0 = childEntry(o, r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, lower, best.t);
+            float t1 = childEntry(o, r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, lower, best.t);
+            float t2 = childEntry(o, r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, lower, best.t);
+            float t3 = childEntry(o, r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, lower, best.t);
+            if (c0 == NONE) t0 = INFINITY;
+            if (c1 == NONE) t1 = INFINITY;
+            if (c2 == NONE) t2 = INFINITY;
+            if (c3 == NONE) t3 = INFINITY;
+            int const nHit = (t0 < INFINITY) + (t1 < INFINITY) + (t2 < INFINITY) + (t3 < INFINITY);
+            if (nHit == 0) {
+                if (sp > 0) {
+                    --sp;
+                    cur = stack[(SPILL ? min(sp, RT_LDS_STACK_DEPTH - 1) : sp) * RT_BLOCK];
+                    if (SPILL && sp >= RT_LDS_STACK_DEPTH) cur = spillStack[sp - RT_LDS_STACK_DEPTH];
+                }
+                else cur = NONE;
+                continue;
+            }
+            // position of each child in ascending (entry, slot) order; children that are missed (+inf) come last
+            int const k0 = (t1 < t0) + (t2 < t0) + (t3 < t0);
+            int const k1 = (t0 <= t1) + (t2 < t1) + (t3 < t1);
+            int const k2 = (t0 <= t2) + (t1 <= t2) + (t3 < t2);
+            int const k3 = (t0 <= t3) + (t1 <= t3) + (t2 <= t3);
+            // the nearest becomes current, the other hit children go on the stack, farthest lowest
+#define RT_BVH_DEFER(k, child)                                                                            \
+            if ((k) >= 1 && (k) < nHit) {                                                                  \
+                int const pos = sp + nHit - 1 - (k);                                                       \
+                if (!SPILL || pos < RT_LDS_STACK_DEPTH) stack[pos * RT_BLOCK] = (child);                   \
+                else spillStack[pos - RT_LDS_STACK_DEPTH] = (child);                                       \
+            }
+            RT_BVH_DEFER(k0, c0)
+            RT_BVH_DEFER(k1, c1)
+            RT_BVH_DEFER(k2, c2)
+            RT_BVH_DEFER(k3, c3)
+#undef RT_BVH_DEFER
+            cur = k0 == 0 ? c0 : (k1 == 0 ? c1 : (k2 == 0 ? c2 : c3));
+            sp += nHit - 1;
+        }
+
+        // ---- phase 2: the leaf's triangles (src/geometry.hpp:99-132, one lane of the 8-wide form) -------
+        if (cur != NONE) {
+            uint32_t const first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
+            if (COUNT) { c.leafVisits++; c.trisTested += count; }
+            for (uint32_t j = 0; j < count; ++j) {
+                float4 const* tp = S.leafTris + 3 * static_cast<size_t>(first + j);
+                float4 a = tp[0];
+                asm volatile("" : "+v"(a.w));       // keep the first fetch one 16-byte load
+                V3 const nrm = mk(a.x, a.y, a.z);
+                float const negDet = dotF(nrm, d);
+                bool const detOk = FRONT_ONLY ? (negDet <= -1e-6f) : (fabsf(negDet) >= 1e-6f);
+                if (!detOk) continue;
+                float4 const b = tp[1], e = tp[2];
+                V3 const v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x), e12 = mk(e.y, e.z, e.w);
+                V3 const AO = o - v1;
+                V3 const DAO = crossF(AO, d);
+                float const du = dotF(e13, DAO);
+                float const dv = dotF(e12, DAO);
+                if (FRONT_ONLY) {
+                    // signs of the barycentric numerators decide most rejections without the division
+                    // (same argument as in traceStream's first pass)
+                    bool const tame = negDet > -0x1p60f;
+                    if ((du < -0x1p-60f || dv > 0x1p-60f) && tame) continue;
+                }
+                float const invDet = -1.0f / negDet;
+                float const u = du * invDet;
+                float const v = (0.0f - dv) * invDet;
+                if (!(u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f)) continue;
+                float const t = dotF(AO, nrm) * invDet;
+                if (!(t >= tMin)) continue;
+                // equal t (coplanar, overlapping triangles): the lower scene-wide triangle index wins, which makes the
+                // result independent of the order in which leaves are visited
+                if (t < best.t || (t == best.t && best.ref != NONE && S.leafIds[first + j].z < S.leafIds[best.ref].z)) {
+                    best.t = t; best.u = u; best.v = v; best.ref = first + j;
+                }
+            }
+            if (sp > 0) {
+                --sp;
+                cur = stack[(SPILL ? min(sp, RT_LDS_STACK_DEPTH - 1) : sp) * RT_BLOCK];
+                if (SPILL && sp >= RT_LDS_STACK_DEPTH) cur = spillStack[sp - RT_LDS_STACK_DEPTH];
+            }
+            else cur = NONE;
+        }
+        if (cur == NONE) {
+            store(line, best, o, d);
+            active = false;
+        }
+    }
+}
+
 // Philox-4x32-10 keyed by the render seed; counter = (pixel index, sample index, dimension pair, 0).
 __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1, uint32_t& r0,
                                        uint32_t& r1, uint32_t& r2) {
@@ -558,6 +745,35 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DevScene S, const float*
                                                         uint32_t* __restrict__ nextLine) {
     Counters c = {};
     traceStream<FRONT_ONLY, false, SPILL>(
+        S, n, nextLine, tMin, c,
+        [&](uint32_t i, V3& o, V3& d) {
+            o = mk(origins[3 * static_cast<size_t>(i)], origins[3 * static_cast<size_t>(i) + 1], origins[3 * static_cast<size_t>(i) + 2]);
+            d = mk(directions[3 * static_cast<size_t>(i)], directions[3 * static_cast<size_t>(i) + 1], directions[3 * static_cast<size_t>(i) + 2]);
+        },
+        [&](uint32_t i, HitRec const& h, V3 o, V3 d) {
+            rt_hit r;
+            if (h.ref != 0xFFFFFFFFu) {
+                uint4 const ids = S.leafIds[h.ref];
+                r.t = h.t; r.u = h.u; r.v = h.v;
+                r.point[0] = o.x + h.t * d.x; r.point[1] = o.y + h.t * d.y; r.point[2] = o.z + h.t * d.z;
+                r.mesh = ids.x; r.tri = ids.y;
+            }
+            else {
+                r.t = 0.0f; r.u = 0.0f; r.v = 0.0f;
+                r.point[0] = r.point[1] = r.point[2] = 0.0f;
+                r.mesh = 0xFFFFFFFFu; r.tri = 0xFFFFFFFFu;
+            }
+            out[i] = r;
+        });
+}
+
+template <bool FRONT_ONLY, bool SPILL>
+__global__ __launch_bounds__(RT_BLOCK) void k_intersect_bvh(DevScene S, const float* __restrict__ origins,
+                                                            const float* __restrict__ directions, uint32_t n,
+                                                            float tMin, rt_hit* __restrict__ out,
+                                                            uint32_t* __restrict__ nextLine) {
+    Counters c = {};
+    traceStreamBvh<FRONT_ONLY, false, SPILL>(
         S, n, nextLine, tMin, c,
         [&](uint32_t i, V3& o, V3& d) {
             o = mk(origins[3 * static_cast<size_t>(i)], origins[3 * static_cast<size_t>(i) + 1], origins[3 * static_cast<size_t>(i) + 2]);
@@ -678,6 +894,28 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, PathState P, uin
     uint32_t const* __restrict__ q = P.queue[bounce & 1];
     Counters c = {};
     traceStream<true, COUNT, SPILL>(
+        S, n, P.counts + RT_FETCH_BASE + bounce, tMin, c,
+        [&](uint32_t i, V3& o, V3& d) {
+            uint32_t const slot = bounce == 0 ? i : q[i];
+            float4 const A = P.A[slot], B = P.B[slot];
+            o = mk(A.x, A.y, A.z);
+            d = mk(A.w, B.x, B.y);
+        },
+        [&](uint32_t i, HitRec const& h, V3, V3) {
+            uint32_t const slot = bounce == 0 ? i : q[i];
+            P.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.ref));
+        });
+    if (COUNT) flushCounters(c, gc);
+}
+
+// The same query answered from the bounding volume hierarchy (S.nodes, S.leafTris, S.leafIds then describe it).
+template <bool COUNT, bool SPILL>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_bvh(DevScene S, PathState P, uint32_t bounce, float tMin,
+                                                        Counters* __restrict__ gc) {
+    uint32_t const n = P.counts[bounce];
+    uint32_t const* __restrict__ q = P.queue[bounce & 1];
+    Counters c = {};
+    traceStreamBvh<true, COUNT, SPILL>(
         S, n, P.counts + RT_FETCH_BASE + bounce, tMin, c,
         [&](uint32_t i, V3& o, V3& d) {
             uint32_t const slot = bounce == 0 ? i : q[i];
@@ -951,7 +1189,7 @@ struct rt_scene {
     void* dTriNormals = nullptr;
     void* dMaterials = nullptr;
     uint64_t deviceBytes = 0;
-    uint32_t nodeCount = 0, leafTriCount = 0, depth = 0, modelCount = 0;
+    uint32_t nodeCount = 0, leafTriCount = 0, depth = 0, modelCount = 0, pretriCount = 0;
     int cuCount = 256;
     Workspace ws;                       // grown on demand by rt_render_device
     Workspace wsStatic;                 // views into this GPU's copy of `scratch`
@@ -960,6 +1198,15 @@ struct rt_scene {
     // that no later call has to query or allocate.
     int gridTrace[2][2] = {{0, 0}, {0, 0}};
     int gridIntersect[2][2] = {{0, 0}, {0, 0}};
+    // Alternative accelerator (rt_scene_attach_bvh4): same DevScene with nodes, leafTris and leafIds replaced.
+    bool hasBvh = false;
+    DevScene devBvh{};
+    void* dBvhNodes = nullptr;
+    void* dBvhTris = nullptr;
+    void* dBvhIds = nullptr;
+    uint32_t bvhStackNeed = 0, bvhNodeCount = 0;
+    int gridTraceBvh[2][2] = {{0, 0}, {0, 0}};
+    int gridIntersectBvh[2][2] = {{0, 0}, {0, 0}};
     // Events of RT_FLAG_PROFILE_KERNELS, kept for reuse across calls.
     std::vector<hipEvent_t> eventPool;
     // All device work of a handle shares one workspace; a call on another stream first waits for the
@@ -1239,6 +1486,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     s->leafTriCount = refCount;
     s->depth = maxDepth;
     s->modelCount = D->model_count;
+    s->pretriCount = D->pretri_count;
     s->gridTrace[0][0] = residentBlocks(s, k_trace<false, false>, false);
     s->gridTrace[0][1] = residentBlocks(s, k_trace<false, true>, true);
     s->gridTrace[1][0] = residentBlocks(s, k_trace<true, false>, false);
@@ -1250,6 +1498,111 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     int const rc = bindStaticWorkspace(s);
     if (rc != RT_OK) return rc;
     *out = holder.release();
+    return RT_OK;
+}
+
+void freeBvh(rt_scene* s) {
+    for (void* p : {s->dBvhNodes, s->dBvhTris, s->dBvhIds})
+        if (p) (void)hipFree(p);
+    s->dBvhNodes = s->dBvhTris = s->dBvhIds = nullptr;
+    s->hasBvh = false;
+}
+
+int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, uint32_t nodeCount, const uint32_t* order) {
+    if (!s || !D || !nodes || nodeCount == 0) return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: null argument");
+    if (D->pretri_count && (!D->pretris || !order || !D->model_pretri_begin))
+        return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: the description must carry pretris and the triangle order");
+    if (D->model_count != s->modelCount || D->pretri_count != s->pretriCount)
+        return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: the description is not the one the scene was created from");
+    uint32_t const triCount = D->pretri_count;
+    if (triCount >= (1u << 28) - 1u) return fail(RT_ERR_LIMIT, "rt_scene_attach_bvh4: more than 2^28 triangles");
+    // ---- validate what the kernels assume ---------------------------------------------------------------
+    std::vector<uint32_t> need(nodeCount, 0u);
+    std::vector<uint8_t> referenced(nodeCount, 0);
+    std::vector<uint8_t> covered(std::max<uint32_t>(triCount, 1), 0);
+    for (uint32_t i = nodeCount; i-- > 0;) {
+        uint32_t present = 0, deepest = 0;
+        for (int k = 0; k < 4; ++k) {
+            uint32_t const c = nodes[i].child[k];
+            if (c == 0xFFFFFFFFu) continue;
+            ++present;
+            if (c & 0x80000000u) {
+                uint32_t const first = c & 0x0FFFFFFFu, count = ((c >> 28) & 7u) + 1u;
+                if (static_cast<uint64_t>(first) + count > triCount) return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: leaf range outside the triangle order");
+                for (uint32_t j = first; j < first + count; ++j) {
+                    if (covered[j]) return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: triangle in two leaves");
+                    covered[j] = 1;
+                }
+            }
+            else {
+                if (c <= i || c >= nodeCount) return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: child number not above its parent's or out of range");
+                if (referenced[c]) return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: node referenced twice");
+                referenced[c] = 1;
+                deepest = std::max(deepest, need[c]);
+            }
+        }
+        need[i] = (present ? present - 1u : 0u) + deepest;
+    }
+    for (uint32_t i = 1; i < nodeCount; ++i)
+        if (!referenced[i]) return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: unreachable node");
+    for (uint32_t j = 0; j < triCount; ++j)
+        if (!covered[j]) return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: triangle in no leaf");
+    if (need[0] > RT_STACK_MAX)
+        return fail(RT_ERR_LIMIT, "rt_scene_attach_bvh4: a descent can defer " + std::to_string(need[0]) + " children, more than the "
+                    + std::to_string(RT_STACK_MAX) + "-entry traversal stack");
+    // ---- triangle records and ids in the hierarchy's order -----------------------------------------------
+    std::vector<float> tris(12 * static_cast<size_t>(std::max<uint32_t>(triCount, 1)), 0.0f);
+    std::vector<uint32_t> ids(4 * static_cast<size_t>(std::max<uint32_t>(triCount, 1)), 0u);
+    {
+        std::vector<uint8_t> used(std::max<uint32_t>(triCount, 1), 0);
+        uint32_t model = 0;
+        std::vector<uint32_t> modelOf(std::max<uint32_t>(triCount, 1), 0u);
+        for (uint32_t g = 0; g < triCount; ++g) {
+            while (model + 1 < D->model_count && g >= D->model_pretri_begin[model + 1]) ++model;
+            modelOf[g] = model;
+        }
+        for (uint32_t k = 0; k < triCount; ++k) {
+            uint32_t const g = order[k];
+            if (g >= triCount || used[g]) return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: tri_order is not a permutation");
+            used[g] = 1;
+            std::memcpy(tris.data() + 12 * static_cast<size_t>(k), D->pretris + 12 * static_cast<size_t>(g), 48);
+            uint32_t const m = modelOf[g];
+            uint32_t const rec[4] = {m, g - D->model_pretri_begin[m], g, 0u};
+            std::memcpy(ids.data() + 4 * static_cast<size_t>(k), rec, 16);
+        }
+    }
+    // ---- upload ---------------------------------------------------------------------------------------------
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->hasLastStream) HIP_TRY(hipStreamSynchronize(s->lastStream));
+    freeBvh(s);
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 128));
+        if (e != hipSuccess) return e;
+        s->deviceBytes += bytes;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t e = upload(&s->dBvhNodes, nodes, sizeof(rt_bvh4_node) * static_cast<size_t>(nodeCount));
+    if (e == hipSuccess) e = upload(&s->dBvhTris, tris.data(), tris.size() * 4);
+    if (e == hipSuccess) e = upload(&s->dBvhIds, ids.data(), ids.size() * 4);
+    if (e != hipSuccess) {
+        freeBvh(s);
+        return fail(RT_ERR_HIP, std::string("rt_scene_attach_bvh4: upload failed: ") + hipGetErrorString(e));
+    }
+    s->devBvh = s->dev;
+    s->devBvh.nodes = static_cast<const float4*>(s->dBvhNodes);
+    s->devBvh.leafTris = static_cast<const float4*>(s->dBvhTris);
+    s->devBvh.leafIds = static_cast<const uint4*>(s->dBvhIds);
+    s->bvhStackNeed = need[0];
+    s->bvhNodeCount = nodeCount;
+    s->gridTraceBvh[0][0] = residentBlocks(s, k_trace_bvh<false, false>, true);
+    s->gridTraceBvh[0][1] = residentBlocks(s, k_trace_bvh<false, true>, true);
+    s->gridTraceBvh[1][0] = residentBlocks(s, k_trace_bvh<true, false>, true);
+    s->gridTraceBvh[1][1] = residentBlocks(s, k_trace_bvh<true, true>, true);
+    s->gridIntersectBvh[0][0] = residentBlocks(s, k_intersect_bvh<false, false>, true);
+    s->gridIntersectBvh[0][1] = residentBlocks(s, k_intersect_bvh<false, true>, true);
+    s->gridIntersectBvh[1][0] = residentBlocks(s, k_intersect_bvh<true, false>, true);
+    s->gridIntersectBvh[1][1] = residentBlocks(s, k_intersect_bvh<true, true>, true);
+    s->hasBvh = true;
     return RT_OK;
 }
 
@@ -1302,8 +1655,10 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
     // 2 072 with 4, 2 098 with 1).
     uint32_t slotGroup = 1u;
     if (const char* text = std::getenv("RT_AMD_SLOT_GROUP")) slotGroup = static_cast<uint32_t>(std::max(1, std::atoi(text)));
-    bool const spill = s->depth > RT_LDS_STACK_DEPTH;
-    int const traceCap = s->gridTrace[countWork ? 1 : 0][spill ? 1 : 0];
+    bool const bvh = (p->flags & RT_FLAG_ACCEL_BVH) != 0;
+    bool const spill = bvh ? s->bvhStackNeed > RT_LDS_STACK_DEPTH : s->depth > RT_LDS_STACK_DEPTH;
+    int const traceCap = (bvh ? s->gridTraceBvh : s->gridTrace)[countWork ? 1 : 0][spill ? 1 : 0];
+    DevScene const& dev = bvh ? s->devBvh : s->dev;
     for (uint32_t done = 0; done < p->spp; done += spb) {
         uint32_t const nb = std::min(spb, p->spp - done);
         uint32_t const paths = static_cast<uint32_t>(pixels * nb);
@@ -1317,14 +1672,20 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
         mark(-1);
         for (uint32_t b = 0; b < bounceCount; ++b) {
             mark(1);
-#define RT_LAUNCH_TRACE(COUNT, SPILL)                                                                         \
-    hipLaunchKernelGGL((k_trace<COUNT, SPILL>), dim3(traceGrid), dim3(RT_BLOCK), 0, st, s->dev, P, b, p->t_min, gc)
-            if (countWork) { if (spill) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
-            else { if (spill) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
+#define RT_LAUNCH_TRACE(KERNEL, COUNT, SPILL)                                                                 \
+    hipLaunchKernelGGL((KERNEL<COUNT, SPILL>), dim3(traceGrid), dim3(RT_BLOCK), 0, st, dev, P, b, p->t_min, gc)
+            if (bvh) {
+                if (countWork) { if (spill) RT_LAUNCH_TRACE(k_trace_bvh, true, true); else RT_LAUNCH_TRACE(k_trace_bvh, true, false); }
+                else { if (spill) RT_LAUNCH_TRACE(k_trace_bvh, false, true); else RT_LAUNCH_TRACE(k_trace_bvh, false, false); }
+            }
+            else {
+                if (countWork) { if (spill) RT_LAUNCH_TRACE(k_trace, true, true); else RT_LAUNCH_TRACE(k_trace, true, false); }
+                else { if (spill) RT_LAUNCH_TRACE(k_trace, false, true); else RT_LAUNCH_TRACE(k_trace, false, false); }
+            }
 #undef RT_LAUNCH_TRACE
             mark(-1);
             mark(2);
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, s->dev, R, P, b, done, M, gc);
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, dev, R, P, b, done, M, gc);
             mark(-1);
             ++traceLaunches;
         }
@@ -1380,6 +1741,8 @@ int checkRenderParams(const rt_scene* s, const rt_render_params* p, const float*
     if (static_cast<uint64_t>(p->width) * p->height > 0xFFFFFFFFull)
         return fail(RT_ERR_LIMIT, "rt_render: more than 2^32 pixels");
     if (p->bounce_limit > 500 || p->bounce_limit + 3 > RT_FETCH_BASE) return fail(RT_ERR_LIMIT, "rt_render: bounce_limit above 500");
+    if ((p->flags & RT_FLAG_ACCEL_BVH) && !s->hasBvh)
+        return fail(RT_ERR_INVALID, "rt_render: RT_FLAG_ACCEL_BVH without a hierarchy attached (rt_scene_attach_bvh4)");
     return RT_OK;
 }
 
@@ -1388,7 +1751,7 @@ int checkRenderParams(const rt_scene* s, const rt_render_params* p, const float*
 extern "C" {
 
 const char* rt_last_error(void) { return g_lastError.c_str(); }
-uint32_t rt_abi_version(void) { return 5; }
+uint32_t rt_abi_version(void) { return 6; }
 
 int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     return guarded("rt_scene_create", [&] { return sceneCreate(D, device, out); });
@@ -1399,11 +1762,35 @@ void rt_scene_destroy(rt_scene* s) {
     (void)hipSetDevice(s->device);
     if (s->hasLastStream) (void)hipStreamSynchronize(s->lastStream);
     freeWorkspace(s);
+    freeBvh(s);
     for (void* p : {s->dNodes, s->dLeafTris, s->dLeafIds, s->dTriNormals, s->dMaterials, static_cast<void*>(s->ws.counts),
                     static_cast<void*>(s->ws.counters), s->wsOut})
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : s->eventPool) (void)hipEventDestroy(ev);
     delete s;
+}
+
+int rt_scene_attach_bvh4(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, uint32_t node_count,
+                         const uint32_t* tri_order) {
+    return guarded("rt_scene_attach_bvh4", [&] { return attachBvh(s, D, nodes, node_count, tri_order); });
+}
+
+int rt_scene_build_bvh4(rt_scene* s, const rt_scene_desc* D, uint32_t max_leaf_tris, int threads) {
+    return guarded("rt_scene_build_bvh4", [&]() -> int {
+        if (!s || !D) return fail(RT_ERR_INVALID, "rt_scene_build_bvh4: null argument");
+        if (D->pretri_count && !D->pretris) return fail(RT_ERR_INVALID, "rt_scene_build_bvh4: the description must carry pretris");
+        rt_bvh4* bvh = nullptr;
+        int rc = rt_bvh4_build(D->pretris, D->pretri_count, max_leaf_tris, threads, &bvh);
+        if (rc != RT_OK) return rc;
+        const rt_bvh4_node* nodes = nullptr;
+        const uint32_t* order = nullptr;
+        uint32_t counts[6] = {};
+        rt_bvh4_view(bvh, &nodes, &order);
+        rt_bvh4_counts(bvh, counts);
+        rc = attachBvh(s, D, nodes, counts[0], order);
+        rt_bvh4_destroy(bvh);
+        return rc;
+    });
 }
 
 int rt_scene_info(const rt_scene* s, uint64_t* device_bytes, uint32_t* node_count, uint32_t* leaf_tri_count,
@@ -1426,17 +1813,27 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
     if (rcs != RT_OK) return rcs;
     // The kernel hands out lines through a 32-bit cursor: larger batches go in slices.
     uint64_t const slice = 0xF0000000ull;
-    bool const spill = s->depth > RT_LDS_STACK_DEPTH;
-    int const cap = s->gridIntersect[front_only ? 1 : 0][spill ? 1 : 0];
+    bool const bvh = (front_only & RT_INTERSECT_BVH) != 0;
+    bool const front = (front_only & ~RT_INTERSECT_BVH) != 0;
+    if (bvh && !s->hasBvh) return fail(RT_ERR_INVALID, "rt_intersect: RT_INTERSECT_BVH without a hierarchy attached (rt_scene_attach_bvh4)");
+    bool const spill = bvh ? s->bvhStackNeed > RT_LDS_STACK_DEPTH : s->depth > RT_LDS_STACK_DEPTH;
+    int const cap = (bvh ? s->gridIntersectBvh : s->gridIntersect)[front ? 1 : 0][spill ? 1 : 0];
+    DevScene const& dev = bvh ? s->devBvh : s->dev;
     for (uint64_t done = 0; done < n; done += slice) {
         uint32_t const m = static_cast<uint32_t>(std::min<uint64_t>(slice, n - done));
         uint32_t* cursor = reinterpret_cast<uint32_t*>(s->ws.counters) + 64;     // behind the Counters block
         HIP_TRY(hipMemsetAsync(cursor, 0, 4, st));
-#define RT_LAUNCH_INTERSECT(FRONT, SPILL)                                                                     \
-    hipLaunchKernelGGL((k_intersect<FRONT, SPILL>), dim3(persistentGrid(cap, m)), dim3(RT_BLOCK), 0, st, s->dev,  \
+#define RT_LAUNCH_INTERSECT(KERNEL, FRONT, SPILL)                                                             \
+    hipLaunchKernelGGL((KERNEL<FRONT, SPILL>), dim3(persistentGrid(cap, m)), dim3(RT_BLOCK), 0, st, dev,       \
                        d_origins + 3 * done, d_directions + 3 * done, m, t_min, d_out + done, cursor)
-        if (front_only) { if (spill) RT_LAUNCH_INTERSECT(true, true); else RT_LAUNCH_INTERSECT(true, false); }
-        else { if (spill) RT_LAUNCH_INTERSECT(false, true); else RT_LAUNCH_INTERSECT(false, false); }
+        if (bvh) {
+            if (front) { if (spill) RT_LAUNCH_INTERSECT(k_intersect_bvh, true, true); else RT_LAUNCH_INTERSECT(k_intersect_bvh, true, false); }
+            else { if (spill) RT_LAUNCH_INTERSECT(k_intersect_bvh, false, true); else RT_LAUNCH_INTERSECT(k_intersect_bvh, false, false); }
+        }
+        else {
+            if (front) { if (spill) RT_LAUNCH_INTERSECT(k_intersect, true, true); else RT_LAUNCH_INTERSECT(k_intersect, true, false); }
+            else { if (spill) RT_LAUNCH_INTERSECT(k_intersect, false, true); else RT_LAUNCH_INTERSECT(k_intersect, false, false); }
+        }
 #undef RT_LAUNCH_INTERSECT
     }
     HIP_TRY(hipGetLastError());

@@ -69,6 +69,32 @@ def serialize_scene(ray_trace_data):
     return blob
 
 
+class Bvh4:
+    """rt_bvh4_build: the alternative accelerator, a 4-wide bounding volume hierarchy over preprocessed
+    triangles (12 floats each), built on the host.  `nodes` (BVH4_NODE_DTYPE) and `tri_order` are copies."""
+
+    def __init__(self, pretris, max_leaf_tris=4, threads=0):
+        L = _lib.lib()
+        pt = np.ascontiguousarray(pretris, np.float32).reshape(-1, 12)
+        h = _lib.vp()
+        _lib.check(L.rt_bvh4_build(ptr(pt), c_u32(len(pt)), c_u32(max_leaf_tris), c_int(threads), ctypes.byref(h)))
+        try:
+            counts = (c_u32 * 6)()
+            L.rt_bvh4_counts(h, counts)
+            (self.node_count, self.tri_count, self.depth, self.stack_need, self.leaf_count,
+             self.largest_leaf) = [int(x) for x in counts]
+            pn, po = _lib.vp(), _lib.vp()
+            L.rt_bvh4_view(h, ctypes.byref(pn), ctypes.byref(po))
+            raw = ctypes.string_at(pn.value, 128 * self.node_count)
+            self.nodes = np.frombuffer(raw, _lib.BVH4_NODE_DTYPE).copy()
+            if self.tri_count:
+                self.tri_order = np.frombuffer(ctypes.string_at(po.value, 4 * self.tri_count), np.uint32).copy()
+            else:
+                self.tri_order = np.zeros(0, np.uint32)
+        finally:
+            L.rt_bvh4_destroy(h)
+
+
 class DeviceScene:
     """A scene resident in HBM (rt_scene).  One per GPU."""
 
@@ -83,11 +109,44 @@ class DeviceScene:
             _lib.check(L.rt_scene_create(ctypes.byref(desc), c_int(device), ctypes.byref(self._h)))
             del keep
         self.device = device
+        self._source = (ray_trace_data, blob)
+        self.has_bvh = False
+        self._refresh_info()
+
+    def _refresh_info(self):
+        L = _lib.lib()
         nbytes, nodes, ltris, depth = c_u64(), c_u32(), c_u32(), c_u32()
         _lib.check(L.rt_scene_info(self._h, ctypes.byref(nbytes), ctypes.byref(nodes), ctypes.byref(ltris),
                                    ctypes.byref(depth)))
         self.device_bytes, self.node_count, self.leaf_tri_count, self.depth = (nbytes.value, nodes.value,
                                                                                ltris.value, depth.value)
+
+    def _desc(self):
+        rtd, blob = self._source
+        if rtd is not None:
+            return _describe(rtd)
+        desc = _lib.RtSceneDesc()
+        _lib.check(_lib.lib().rt_scene_desc_from_blob(ptr(blob), c_u64(blob.size), ctypes.byref(desc)))
+        return desc, blob
+
+    def build_bvh(self, max_leaf_tris=4, threads=0):
+        """rt_scene_build_bvh4: build the 4-wide bounding volume hierarchy over the scene's triangles and
+        attach it; RT_FLAG_ACCEL_BVH / intersect(use_bvh=True) then answer queries from it."""
+        desc, keep = self._desc()
+        _lib.check(_lib.lib().rt_scene_build_bvh4(self._h, ctypes.byref(desc), c_u32(max_leaf_tris), c_int(threads)))
+        del keep
+        self.has_bvh = True
+        self._refresh_info()
+
+    def attach_bvh(self, nodes, tri_order):
+        """rt_scene_attach_bvh4 with caller-supplied nodes (BVH4_NODE_DTYPE) and triangle order."""
+        desc, keep = self._desc()
+        nodes = np.ascontiguousarray(nodes, _lib.BVH4_NODE_DTYPE)
+        order = np.ascontiguousarray(tri_order, np.uint32)
+        _lib.check(_lib.lib().rt_scene_attach_bvh4(self._h, ctypes.byref(desc), ptr(nodes), c_u32(len(nodes)), ptr(order)))
+        del keep
+        self.has_bvh = True
+        self._refresh_info()
 
     @classmethod
     def from_blob(cls, blob, device=0):
@@ -106,13 +165,14 @@ class DeviceScene:
             pass
 
     # BSPTree::lineTriNearestIntersection<Surfaces>, src/bsp.hpp:50-145
-    def intersect(self, origins, directions, t_min=RAY_INTERSECTION_T_MIN, front_only=True):
+    def intersect(self, origins, directions, t_min=RAY_INTERSECTION_T_MIN, front_only=True, use_bvh=False):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
         assert o.shape == d.shape
         out = np.zeros(len(o), _lib.HIT_DTYPE)
+        mode = (_lib.RT_INTERSECT_FRONT_ONLY if front_only else 0) | (_lib.RT_INTERSECT_BVH if use_bvh else 0)
         _lib.check(_lib.lib().rt_intersect(self._h, ptr(o), ptr(d), c_u64(len(o)), c_f32(t_min),
-                                           c_int(int(front_only)), ptr(out)))
+                                           c_int(mode), ptr(out)))
         return out
 
     def intersect_device(self, d_origins, d_directions, n, d_out, t_min=RAY_INTERSECTION_T_MIN, front_only=True,

@@ -1,0 +1,158 @@
+"""The alternative accelerator on the host: the 4-wide bounding volume hierarchy builder (rt_bvh4_build) and the
+oracle's restatement of its traversal.  The reference has no such accelerator, so what is pinned here is
+(a) structure: every triangle in exactly one leaf, every child box contains its subtree, child numbers ascending;
+(b) the restated traversal returns the nearest triangle that the reference's own triangle test accepts
+    (src/geometry.hpp:99-132; ties: lowest triangle index), bit for bit equal to a scan of all triangles, and
+    equal to the BSP traversal that is pinned to the reference (src/bsp.hpp:50-145) on all but a few rays."""
+import numpy as np
+import pytest
+
+from helpers import base_from_scene
+from oracle import binding
+from raytracing_amd import _lib, render, scenes
+
+NONE = 0xFFFFFFFF
+
+
+def corners(pretris):
+    v1 = pretris[:, 3:6]
+    return np.stack([v1, v1 + pretris[:, 9:12], v1 + pretris[:, 6:9]], 1)      # [n, 3 corners, xyz]
+
+
+def check_structure(b, pretris):
+    nodes, order = b.nodes, b.tri_order
+    assert sorted(order.tolist()) == list(range(len(pretris)))
+    pts = corners(pretris)[order]                                             # hierarchy order
+    lo = np.stack([nodes["lo_x"], nodes["lo_y"], nodes["lo_z"]], -1)          # [node, child, xyz]
+    hi = np.stack([nodes["hi_x"], nodes["hi_y"], nodes["hi_z"]], -1)
+    covered = np.zeros(len(pretris), np.int32)
+    # bounds of every node's subtree, children before parents (child numbers are larger than the parent's)
+    sub_lo = np.full((len(nodes), 3), np.inf, np.float32)
+    sub_hi = np.full((len(nodes), 3), -np.inf, np.float32)
+    leaves = 0
+    for i in range(len(nodes) - 1, -1, -1):
+        for k in range(4):
+            c = int(nodes["child"][i, k])
+            if c == NONE:
+                continue
+            if c & 0x80000000:
+                first, count = c & 0x0FFFFFFF, ((c >> 28) & 7) + 1
+                covered[first:first + count] += 1
+                leaves += 1
+                clo, chi = pts[first:first + count].min((0, 1)), pts[first:first + count].max((0, 1))
+            else:
+                assert i < c < len(nodes)
+                clo, chi = sub_lo[c], sub_hi[c]
+            assert (lo[i, k] <= clo).all() and (hi[i, k] >= chi).all(), (i, k)
+            sub_lo[i] = np.minimum(sub_lo[i], lo[i, k])
+            sub_hi[i] = np.maximum(sub_hi[i], hi[i, k])
+    assert (covered == 1).all()
+    assert leaves == b.leaf_count
+
+
+@pytest.fixture(scope="module")
+def cornell():
+    sc = scenes.cornell_scene().preprocess()
+    return sc, sc.preprocessed_tris.tris
+
+
+def test_structure_and_determinism(cornell):
+    _, pt = cornell
+    for max_leaf in (1, 4, 8):
+        b = render.Bvh4(pt, max_leaf, threads=1)
+        assert b.tri_count == len(pt) and b.largest_leaf <= max_leaf and b.stack_need <= 3 * b.depth
+        check_structure(b, pt)
+    a, c = render.Bvh4(pt, 4, threads=1), render.Bvh4(pt, 4, threads=4)
+    assert np.array_equal(a.nodes, c.nodes) and np.array_equal(a.tri_order, c.tri_order)
+
+
+def test_parallel_build_equals_sequential_on_a_larger_mesh():
+    from raytracing_amd import scene as sm
+    sc = scenes.dragon_scale_scene(80_000)
+    im = sm.instantiate_meshes(sc.meshes.vertex_positions, sc.meshes.vertex_normals, sc.meshes.vertex_ranges,
+                               sc.models.mesh_transforms, sc.models.meshes)
+    pt = sm.preprocess_tris(im.vertex_positions, im.vertex_begin, sc.meshes.tris, sc.meshes.tri_ranges,
+                            sc.models.meshes).tris
+    assert len(pt) > 65536                   # above the builder's parallel grain
+    a, c = render.Bvh4(pt, 4, threads=1), render.Bvh4(pt, 4, threads=8)
+    assert np.array_equal(a.nodes, c.nodes) and np.array_equal(a.tri_order, c.tri_order)
+    check_structure(a, pt)
+
+
+def test_degenerate_inputs():
+    # no triangles: one node without children
+    b = render.Bvh4(np.zeros((0, 12), np.float32))
+    assert b.node_count == 1 and (b.nodes["child"] == NONE).all()
+    # one triangle, and forty coincident triangles (no plane separates their centroids)
+    one = np.array([[0, 0, 1, 0, 0, 0, 0, 1, 0, 1, 0, 0]], np.float32)
+    b = render.Bvh4(one)
+    assert b.node_count == 1 and b.leaf_count == 1
+    check_structure(b, one)
+    many = np.repeat(one, 40, 0)
+    b = render.Bvh4(many, 4)
+    check_structure(b, many)
+    assert b.largest_leaf <= 4
+    with pytest.raises(_lib.RtError):
+        render.Bvh4(one, max_leaf_tris=9)
+    bad = one.copy()
+    bad[0, 3] = np.inf
+    with pytest.raises(_lib.RtError):
+        render.Bvh4(bad)
+
+
+def test_restated_traversal_finds_the_nearest_accepted_triangle(cornell):
+    sc, pt = cornell
+    w, h = 96, 64
+    osc = binding.oracle().scene_create_with_tree(base_from_scene(sc), w, h, sc.bsp_tree)
+    try:
+        b = render.Bvh4(pt, 4)
+        osc.set_bvh4(b.nodes, b.tri_order)
+        rng = np.random.default_rng(5)
+        xy = np.stack([rng.uniform(0, w, 3000), rng.uniform(0, h, 3000)], 1).astype(np.float32)
+        d = osc.camera_rays(xy)
+        o = np.tile(np.asarray(sc.camera.position, np.float32), (len(d), 1))
+        f_bsp, id_bsp = osc.intersect(o, d)
+        f_bvh, id_bvh = osc.intersect(o, d, use_bvh=True)
+        # second generation: from the hit points into random directions (incoherent, origins on surfaces)
+        hit = id_bsp[:, 0] != NONE
+        o2 = f_bsp[hit, 3:6]
+        d2 = rng.normal(size=o2.shape).astype(np.float32)
+        d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+        g_bsp, gid_bsp = osc.intersect(o2, d2)
+        g_bvh, gid_bvh = osc.intersect(o2, d2, use_bvh=True)
+        for fa, ia, fb, ib, oo, dd in ((f_bsp, id_bsp, f_bvh, id_bvh, o, d), (g_bsp, gid_bsp, g_bvh, gid_bvh, o2, d2)):
+            # (1) the hierarchy's answer IS the nearest accepted triangle: equal, bit for bit, to a scan of all
+            # triangles with the reference's test
+            fc, ic = osc.intersect_brute(oo, dd)
+            assert np.array_equal(ib, ic) and np.array_equal(fb.view(np.uint32), fc.view(np.uint32))
+            # (2) and it agrees with the BSP traversal except where the BSP's in-leaf-box rule drops a hit
+            # (src/bsp.hpp:82-87), which can only make the BSP's answer farther
+            same = (ia == ib).all(1) & (fa.view(np.uint32) == fb.view(np.uint32)).all(1)
+            assert same.mean() > 0.999, same.mean()
+            diff = ~same
+            t_a = np.where(ia[:, 0] == NONE, np.inf, fa[:, 0])
+            t_b = np.where(ib[:, 0] == NONE, np.inf, fb[:, 0])
+            assert (t_b[diff] <= t_a[diff]).all()
+    finally:
+        osc.close()
+
+
+def test_front_and_back_surfaces(cornell):
+    sc, pt = cornell
+    osc = binding.oracle().scene_create_with_tree(base_from_scene(sc), 64, 64, sc.bsp_tree)
+    try:
+        b = render.Bvh4(pt, 2)
+        osc.set_bvh4(b.nodes, b.tri_order)
+        rng = np.random.default_rng(9)
+        o = rng.uniform(-0.9, 0.9, (2000, 3)).astype(np.float32)
+        d = rng.normal(size=o.shape).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        for front in (True, False):
+            fa, ia = osc.intersect(o, d, front_only=front)
+            fb, ib = osc.intersect(o, d, front_only=front, use_bvh=True)
+            fc, ic = osc.intersect_brute(o, d, front_only=front)
+            assert np.array_equal(ib, ic) and np.array_equal(fb.view(np.uint32), fc.view(np.uint32))
+            same = (ia == ib).all(1) & (fa.view(np.uint32) == fb.view(np.uint32)).all(1)
+            assert same.mean() > 0.999
+    finally:
+        osc.close()

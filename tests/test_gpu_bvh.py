@@ -1,0 +1,218 @@
+"""The alternative accelerator on the GPU (RT_FLAG_ACCEL_BVH, RT_INTERSECT_BVH): the 4-wide bounding volume
+hierarchy behind the same nearest-intersection query.  The reference has no such accelerator; what is checked:
+  * the GPU traversal equals the oracle's restatement of it bit for bit (hits, rendered radiance, work counters);
+  * its answer is the nearest triangle the reference's triangle test accepts (src/geometry.hpp:99-132): bit-equal
+    to a scan of all triangles, and bit-equal to the BSP path (src/bsp.hpp:50-145) on all but a few rays in a
+    hundred thousand (the BSP's in-leaf-box rule, src/bsp.hpp:82-87, can drop a hit; the hierarchy cannot);
+  * rendering through it converges to the reference's image inside the same 1/sqrt(n) envelope as the BSP path."""
+import numpy as np
+import pytest
+
+from helpers import base_from_scene, golden, rel_rmse, same_bits
+from oracle import binding
+
+from raytracing_amd import _lib, render, scenes
+from raytracing_amd.render import DeviceScene, RayTraceData
+
+pytestmark = pytest.mark.gpu
+NONE = 0xFFFFFFFF
+
+
+def _check_hits(hits, floats, ids):
+    assert np.array_equal(hits["mesh"], ids[:, 0]) and np.array_equal(hits["tri"], ids[:, 1])
+    got = np.concatenate([np.stack([hits["t"], hits["u"], hits["v"]], 1), hits["point"]], 1)
+    assert same_bits(got, floats)
+
+
+def _with_bvh(oracle_lib, sc, w, h, max_leaf=4):
+    sc.preprocess()
+    ds = DeviceScene(RayTraceData(sc))
+    osc = oracle_lib.scene_create_with_tree(base_from_scene(sc), w, h, sc.bsp_tree)
+    b = render.Bvh4(sc.preprocessed_tris.tris, max_leaf)
+    ds.attach_bvh(b.nodes, b.tri_order)
+    osc.set_bvh4(b.nodes, b.tri_order)
+    return ds, osc, b
+
+
+def _rays(sc, osc, w, h, n, seed):
+    rng = np.random.default_rng(seed)
+    xy = np.stack([rng.uniform(0, w, n), rng.uniform(0, h, n)], 1).astype(np.float32)
+    d0 = osc.camera_rays(xy)
+    o0 = np.tile(np.asarray(sc.camera.position, np.float32), (n, 1))
+    f, ids = osc.intersect(o0, d0)
+    hit = ids[:, 0] != NONE
+    o1 = f[hit, 3:6].copy()
+    d1 = rng.standard_normal(o1.shape)
+    d1 = (d1 / np.linalg.norm(d1, axis=1, keepdims=True)).astype(np.float32)
+    return (o0, d0), (o1, d1)
+
+
+@pytest.mark.parametrize("max_leaf", [1, 4, 8])
+def test_hits_equal_restated_traversal_brute_force_and_bsp(oracle_lib, max_leaf):
+    sc = scenes.cornell_scene()
+    ds, osc, b = _with_bvh(oracle_lib, sc, 96, 64, max_leaf)
+    try:
+        for o, d in _rays(sc, osc, 96, 64, 6000, seed=3 + max_leaf):
+            for front in (True, False):
+                for t_min in (1e-3, 0.5):
+                    got = ds.intersect(o, d, t_min, front, use_bvh=True)
+                    f, ids = osc.intersect(o, d, t_min, front, use_bvh=True)
+                    _check_hits(got, f, ids)                                   # GPU == restatement
+                    fb, idb = osc.intersect_brute(o, d, t_min, front)
+                    _check_hits(got, fb, idb)                                  # == scan of all triangles
+                    bsp = ds.intersect(o, d, t_min, front)
+                    same = (bsp["tri"] == got["tri"]) & (bsp["mesh"] == got["mesh"]) & (bsp["t"].view(np.uint32) == got["t"].view(np.uint32))
+                    assert same.mean() > 0.999
+    finally:
+        ds.close(); osc.close()
+
+
+def _assert_same_image_and_work(img, st, oimg, ost):
+    assert same_bits(img, oimg), f"{(img != oimg).sum()} of {img.size} values differ"
+    assert st["segments"] == ost["segments"] and st["paths"] == ost["paths"] and st["shaded_hits"] == ost["shadedHits"]
+    assert st["box_tests"] == ost["boxTests"] and st["tris_tested"] == ost["trisTested"]
+    assert st["leaf_visits"] == ost["leafVisits"] and st["inode_visits"] == ost["inodeVisits"]
+
+
+@pytest.mark.parametrize("bounce_limit,flags", [(0, 0), (8, 0), (12, _lib.RT_FLAG_RUSSIAN_ROULETTE)])
+def test_render_bit_exact_against_restatement(oracle_lib, bounce_limit, flags):
+    sc = scenes.cornell_scene(wall_grid=8, box_grid=3)
+    ds, osc, _ = _with_bvh(oracle_lib, sc, 96, 64)
+    try:
+        w, h = 96, 64
+        p2r = sc.pixel_to_ray_transform(w, h)
+        for count in (_lib.RT_FLAG_COUNT_WORK, 0):
+            p = ds.make_params(w, h, sc.camera.position, p2r, spp=4, bounce_limit=bounce_limit, seed=31,
+                               flags=flags | count | _lib.RT_FLAG_ACCEL_BVH)
+            img, st = ds.render(p)
+            oflags = binding.FLAG_ACCEL_BVH | (binding.FLAG_RUSSIAN_ROULETTE if flags & _lib.RT_FLAG_RUSSIAN_ROULETTE else 0)
+            oimg, ost = osc.render_device_mode(osc.render_params(4, seed=31, bounce_limit=bounce_limit, flags=oflags), threads=16)
+            if count:
+                _assert_same_image_and_work(img, st, oimg, ost)
+            else:
+                assert same_bits(img, oimg) and st["segments"] == ost["segments"]
+        # against the BSP path: the same image except for the few paths whose hit differs
+        bsp, sb = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=4, bounce_limit=bounce_limit, seed=31, flags=flags))
+        differing = (bsp != img).any(-1).mean()
+        assert differing < 0.01, differing
+    finally:
+        ds.close(); osc.close()
+
+
+def test_flag_without_hierarchy_is_an_error_and_attach_validates(oracle_lib):
+    sc = scenes.builtin_scene(3).preprocess()
+    ds = DeviceScene(RayTraceData(sc))
+    try:
+        p = ds.make_params(64, 48, sc.camera.position, sc.pixel_to_ray_transform(64, 48), spp=1, flags=_lib.RT_FLAG_ACCEL_BVH)
+        with pytest.raises(_lib.RtError, match="hierarchy"):
+            ds.render(p)
+        with pytest.raises(_lib.RtError, match="hierarchy"):
+            ds.intersect(np.zeros((1, 3), np.float32), np.ones((1, 3), np.float32), use_bvh=True)
+        b = render.Bvh4(sc.preprocessed_tris.tris, 4)
+        bad = b.nodes.copy()
+        interior = np.argwhere((bad["child"] & 0x80000000) == 0)
+        i, k = interior[0]
+        bad["child"][i, k] = i                             # a node that is its own child
+        with pytest.raises(_lib.RtError, match="child number"):
+            ds.attach_bvh(bad, b.tri_order)
+        order = b.tri_order.copy()
+        order[0] = order[1]
+        with pytest.raises(_lib.RtError, match="permutation"):
+            ds.attach_bvh(b.nodes, order)
+        with pytest.raises(_lib.RtError):
+            ds.attach_bvh(b.nodes[:-1], b.tri_order)       # a child out of range, or a triangle in no leaf
+        ds.build_bvh(4)
+        img, _ = ds.render(p)
+        ref, _ = ds.render(ds.make_params(64, 48, sc.camera.position, sc.pixel_to_ray_transform(64, 48), spp=1))
+        assert (img != ref).any(-1).mean() < 0.01
+    finally:
+        ds.close()
+
+
+def test_empty_scene_and_single_triangle_through_the_hierarchy():
+    from raytracing_amd import scene as S
+    m = S.Models()
+    empty = S.Scene(S.Camera((0, 0, 5), (0, np.pi, 0), 0.8), S.Meshes([]), [], m, inflate_mode=1)
+    im = S.instantiate_meshes(empty.meshes.vertex_positions, empty.meshes.vertex_normals, empty.meshes.vertex_ranges, [], [])
+    empty.instantiated_meshes = im
+    empty.preprocessed_tris = S.preprocess_tris(im.vertex_positions, im.vertex_begin, empty.meshes.tris,
+                                                empty.meshes.tri_ranges, [])
+    empty.preprocessed_materials = np.zeros((0, 12), np.float32)
+    empty.bounding_box = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    empty.bsp_tree = S.BSPTree(im.vertex_positions, im.vertex_begin, empty.meshes.tris, empty.meshes.tri_ranges, [],
+                               empty.bounding_box)
+    ds = DeviceScene(RayTraceData(empty))
+    try:
+        ds.build_bvh(4)
+        p = ds.make_params(32, 16, empty.camera.position, empty.pixel_to_ray_transform(32, 16), spp=2, flags=_lib.RT_FLAG_ACCEL_BVH)
+        img, st = ds.render(p)
+        assert not img.any() and st["segments"] == st["paths"] == 32 * 16 * 2
+    finally:
+        ds.close()
+    tri = (np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32), np.tile(np.array([[0, 0, 1]], np.float32), (3, 1)),
+           np.array([[0, 1, 2]], np.uint32))
+    m = S.Models()
+    m.add(S.MeshTransform(), 0, 0)
+    one = S.Scene(S.Camera((0, 0, 5), (0, np.pi, 0), 0.8), S.Meshes([tri]), [S.Material((0.5,) * 3, 0.5, 0.0, (2, 3, 4))],
+                  m, inflate_mode=1).preprocess()
+    ds = DeviceScene(RayTraceData(one))
+    try:
+        ds.build_bvh(4)
+        p2r = one.pixel_to_ray_transform(64, 64)
+        a, _ = ds.render(ds.make_params(64, 64, one.camera.position, p2r, spp=2, flags=_lib.RT_FLAG_ACCEL_BVH))
+        b, _ = ds.render(ds.make_params(64, 64, one.camera.position, p2r, spp=2))
+        assert same_bits(a, b) and np.allclose(a[32, 32], [2, 3, 4]) and not a[0, 0].any()
+    finally:
+        ds.close()
+
+
+def test_converged_image_through_the_hierarchy():
+    """Same envelope as the BSP path's convergence test: relative RMSE against the reference's 16384-spp render of the
+    built-in scene below 1.25 * 1.17 * sqrt(1/n1 + 1/n2) = 0.026 at 4096 spp, mean radiance within 0.5 %."""
+    sc = scenes.builtin_scene(3).preprocess()
+    ds = DeviceScene(RayTraceData(sc))
+    try:
+        ds.build_bvh(4)
+        g = golden("builtin_converged_160x120.npz")
+        w, h = 160, 120
+        p2r = sc.pixel_to_ray_transform(w, h)
+        img, _ = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=4096, seed=909, flags=_lib.RT_FLAG_ACCEL_BVH))
+        ref = g["image"]
+        assert rel_rmse(img, ref) < 0.026, rel_rmse(img, ref)
+        assert abs(img.mean() / ref.mean() - 1.0) < 0.005
+    finally:
+        ds.close()
+
+
+def test_dragon_scale_scene_through_the_hierarchy(oracle_lib):
+    """0.9 M triangles: hierarchy deeper than the 20 stack entries kept in LDS (the scratch part of the stack is
+    exercised), GPU against the restatement on 60 000 + 60 000 rays and a rendered tile, and against the BSP path."""
+    sc = scenes.dragon_scale_scene(900_000)
+    ds, osc, b = _with_bvh(oracle_lib, sc, 1920, 1080)
+    try:
+        assert b.stack_need > 20
+        w, h = 1920, 1080
+        (o0, d0), (o1, d1) = _rays(sc, osc, w, h, 60_000, seed=8)
+        for o, d in ((o0, d0), (o1, d1)):
+            got = ds.intersect(o, d, use_bvh=True)
+            f, ids = osc.intersect(o, d, use_bvh=True)
+            _check_hits(got, f, ids)
+            bsp = ds.intersect(o, d)
+            same = (bsp["tri"] == got["tri"]) & (bsp["mesh"] == got["mesh"]) & (bsp["t"].view(np.uint32) == got["t"].view(np.uint32))
+            assert same.mean() > 0.9999, same.mean()
+        rect = (900, 500, 96, 64)
+        p2r = sc.pixel_to_ray_transform(w, h)
+        tile, st = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=2, rect=rect,
+                                            flags=_lib.RT_FLAG_COUNT_WORK | _lib.RT_FLAG_ACCEL_BVH))
+        otile, ost = osc.render_device_mode(osc.render_params(2, rect=rect, flags=binding.FLAG_ACCEL_BVH), threads=16)
+        _assert_same_image_and_work(tile, st, otile, ost)
+        # full frame at 1 spp: halves reassemble, and the frame differs from the BSP path's in a few pixels at most
+        full, sf = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, flags=_lib.RT_FLAG_ACCEL_BVH))
+        left, _ = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, rect=(0, 0, 1000, h), flags=_lib.RT_FLAG_ACCEL_BVH))
+        right, _ = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1, rect=(1000, 0, w - 1000, h), flags=_lib.RT_FLAG_ACCEL_BVH))
+        assert same_bits(np.concatenate([left, right], axis=1), full)
+        bsp, sb = ds.render(ds.make_params(w, h, sc.camera.position, p2r, spp=1))
+        assert (bsp != full).any(-1).mean() < 1e-3
+        print("segments bvh/bsp", sf["segments"], sb["segments"])
+    finally:
+        ds.close(); osc.close()
