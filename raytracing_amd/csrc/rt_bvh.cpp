@@ -60,6 +60,7 @@ struct Builder {
     std::vector<Node2> nodes;
     std::atomic<uint32_t> nextNode{1};
     uint32_t maxLeaf = 4;
+    double nodeCost = 1.0;          // cost of one more node visit, in triangle tests
 
     // work queue of subtrees still to split
     struct Task { uint32_t node, first, count, depth; };
@@ -121,7 +122,7 @@ struct Builder {
         if (count <= maxLeaf) {
             // surface area heuristic with unit costs: a leaf of n triangles against one more node visit
             double const area = bounds.area();
-            double const splitCost = (bestAxis >= 0 && area > 0.0) ? 1.0 + bestCost / area : std::numeric_limits<double>::infinity();
+            double const splitCost = (bestAxis >= 0 && area > 0.0) ? nodeCost + bestCost / area : std::numeric_limits<double>::infinity();
             if (double(count) <= splitCost) return makeLeaf();
         }
         if (bestAxis >= 0) {
@@ -211,6 +212,7 @@ int rt_bvh4_build(const float* pretris, uint32_t pretri_count, uint32_t max_leaf
     try {
         Builder B;
         B.maxLeaf = max_leaf_tris;
+        if (const char* text = std::getenv("RT_AMD_BVH_NODE_COST")) B.nodeCost = std::max(0.0, std::atof(text));      // tuning aid
         B.prims.resize(pretri_count);
         float absMax = 0.0f;
         for (uint32_t i = 0; i < pretri_count; ++i) {

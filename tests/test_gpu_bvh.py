@@ -25,13 +25,19 @@ def _check_hits(hits, floats, ids):
 
 
 def _with_bvh(oracle_lib, sc, w, h, max_leaf=4):
-    sc.preprocess()
+    if sc.bsp_tree is None:
+        sc.preprocess()
     ds = DeviceScene(RayTraceData(sc))
     osc = oracle_lib.scene_create_with_tree(base_from_scene(sc), w, h, sc.bsp_tree)
     b = render.Bvh4(sc.preprocessed_tris.tris, max_leaf)
     ds.attach_bvh(b.nodes, b.tri_order)
     osc.set_bvh4(b.nodes, b.tri_order)
     return ds, osc, b
+
+
+@pytest.fixture(scope="module")
+def dragon_inputs():
+    return scenes.dragon_scale_scene(900_000).preprocess()
 
 
 def _rays(sc, osc, w, h, n, seed):
@@ -47,8 +53,11 @@ def _rays(sc, osc, w, h, n, seed):
     return (o0, d0), (o1, d1)
 
 
-@pytest.mark.parametrize("max_leaf", [1, 4, 8])
-def test_hits_equal_restated_traversal_brute_force_and_bsp(oracle_lib, max_leaf):
+@pytest.mark.parametrize("max_leaf,shape", [(1, "0"), (4, "0"), (8, "0"), (2, "1"), (4, "1"), (8, "1")])
+def test_hits_equal_restated_traversal_brute_force_and_bsp(oracle_lib, monkeypatch, max_leaf, shape):
+    """Both shapes of the traversal loop (two-phase for small hierarchies, one step per iteration for large ones;
+    forced here through the library's tuning variable, read when the hierarchy is attached)."""
+    monkeypatch.setenv("RT_AMD_BVH_MERGED", shape)
     sc = scenes.cornell_scene()
     ds, osc, b = _with_bvh(oracle_lib, sc, 96, 64, max_leaf)
     try:
@@ -74,8 +83,9 @@ def _assert_same_image_and_work(img, st, oimg, ost):
     assert st["leaf_visits"] == ost["leafVisits"] and st["inode_visits"] == ost["inodeVisits"]
 
 
-@pytest.mark.parametrize("bounce_limit,flags", [(0, 0), (8, 0), (12, _lib.RT_FLAG_RUSSIAN_ROULETTE)])
-def test_render_bit_exact_against_restatement(oracle_lib, bounce_limit, flags):
+@pytest.mark.parametrize("bounce_limit,flags,shape", [(0, 0, "0"), (8, 0, "0"), (8, 0, "1"), (12, _lib.RT_FLAG_RUSSIAN_ROULETTE, "1")])
+def test_render_bit_exact_against_restatement(oracle_lib, monkeypatch, bounce_limit, flags, shape):
+    monkeypatch.setenv("RT_AMD_BVH_MERGED", shape)
     sc = scenes.cornell_scene(wall_grid=8, box_grid=3)
     ds, osc, _ = _with_bvh(oracle_lib, sc, 96, 64)
     try:
@@ -184,10 +194,12 @@ def test_converged_image_through_the_hierarchy():
         ds.close()
 
 
-def test_dragon_scale_scene_through_the_hierarchy(oracle_lib):
-    """0.9 M triangles: hierarchy deeper than the 20 stack entries kept in LDS (the scratch part of the stack is
+@pytest.mark.parametrize("shape", ["1", "0"])
+def test_dragon_scale_scene_through_the_hierarchy(oracle_lib, dragon_inputs, monkeypatch, shape):
+    """0.9 M triangles (both loop shapes; the one-step shape is what a hierarchy of this size gets by default): hierarchy deeper than the 20 stack entries kept in LDS (the scratch part of the stack is
     exercised), GPU against the restatement on 60 000 + 60 000 rays and a rendered tile, and against the BSP path."""
-    sc = scenes.dragon_scale_scene(900_000)
+    monkeypatch.setenv("RT_AMD_BVH_MERGED", shape)
+    sc = dragon_inputs
     ds, osc, b = _with_bvh(oracle_lib, sc, 1920, 1080)
     try:
         assert b.stack_need > 20

@@ -13,7 +13,13 @@ def run(name, sc, w, h, spp, reps=3, bounce_limit=8):
     ds = DeviceScene(RayTraceData(sc))
     print(f"{name}: {len(sc.preprocessed_tris.tris)} triangles, preprocess+tree {t1 - t0:.1f} s, upload {time.time() - t1:.1f} s, "
           f"depth {ds.depth}, {ds.device_bytes / 1e9:.2f} GB on device", flush=True)
-    p = ds.make_params(w, h, sc.camera.position, sc.pixel_to_ray_transform(w, h), spp=spp, flags=2, bounce_limit=bounce_limit)
+    flags = 2
+    if os.environ.get("RT_ACCEL") == "bvh":          # the alternative accelerator instead of the BSP tree
+        t2 = time.time()
+        ds.build_bvh(int(os.environ.get("RT_BVH_LEAF", "4")))
+        flags |= 8
+        print(f"{name}: hierarchy built and attached in {time.time() - t2:.2f} s", flush=True)
+    p = ds.make_params(w, h, sc.camera.position, sc.pixel_to_ray_transform(w, h), spp=spp, flags=flags, bounce_limit=bounce_limit)
     ds.render(p)
     best = None
     for _ in range(reps):

@@ -12,7 +12,11 @@ sc = {"cornell": scenes.cornell_scene, "builtin": scenes.builtin_scene,
       "dragon100k": lambda: scenes.dragon_scale_scene(100_000), "dragon": scenes.dragon_scale_scene,
       "multi": scenes.multi_mesh_scene}[name]().preprocess()
 ds = DeviceScene(RayTraceData(sc))
-p = ds.make_params(1920, 1080, sc.camera.position, sc.pixel_to_ray_transform(1920, 1080), spp=spp, bounce_limit=bounce)
+flags = 0
+if os.environ.get("RT_ACCEL") == "bvh":          # the alternative accelerator instead of the BSP tree
+    ds.build_bvh(int(os.environ.get("RT_BVH_LEAF", "4")))
+    flags = 8
+p = ds.make_params(1920, 1080, sc.camera.position, sc.pixel_to_ray_transform(1920, 1080), spp=spp, bounce_limit=bounce, flags=flags)
 img, st = ds.render(p)
 print(name, st["segments"], st["ms_total"])
 if len(sys.argv) > 3:
