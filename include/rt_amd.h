@@ -83,15 +83,19 @@ typedef struct {
 typedef struct rt_scene rt_scene;
 
 /* One node of the alternative accelerator, a 4-wide bounding volume hierarchy (no counterpart in the
- * reference, whose only accelerator is BSPTree, src/bsp.hpp:35-48).  128 bytes: the boxes of up to four
- * children as a structure of arrays, then the child references.  child[k] == 0xFFFFFFFF: no child;
- * bit 31 set: a leaf, triangles [first, first+count) of the hierarchy's triangle order with
- * first = bits 0-27 and count-1 = bits 28-30; otherwise the number of an interior node, always larger
- * than the node's own number (node 0 is the root). */
+ * reference, whose only accelerator is BSPTree, src/bsp.hpp:35-48).  64 bytes.  The boxes of up to four
+ * children are stored as 8-bit offsets from the node's own lower corner: plane = origin[a] + q * 2^(exp[a]-127),
+ * rounded outwards by the builder, so a stored box always contains the child's triangles.
+ * child[k] == 0xFFFFFFFF: no child; bit 31 set: a leaf, triangles [first, first+count) of the hierarchy's
+ * triangle order with first = bits 0-27 and count-1 = bits 28-30; otherwise the number of an interior node,
+ * always larger than the node's own number (node 0 is the root). */
 typedef struct {
-    float lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4];
+    float origin[3];
+    uint8_t exp[3];               /* per axis: IEEE-754 exponent field of the quantisation step */
+    uint8_t pad0_;
+    uint8_t qlo_x[4], qlo_y[4], qlo_z[4], qhi_x[4], qhi_y[4], qhi_z[4];      /* byte k: child k */
+    uint32_t pad1_[2];
     uint32_t child[4];
-    uint32_t pad_[4];
 } rt_bvh4_node;
 
 /* LineMeshIntersection (src/bsp.hpp:23-29).  mesh == 0xFFFFFFFF marks "no intersection"

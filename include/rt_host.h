@@ -103,7 +103,7 @@ void rt_bsp_view(const rt_bsp* bsp, float root_box[6], int32_t* root_index, cons
 
 /* Builder of the alternative accelerator (rt_bvh4_node, rt_amd.h): binned surface-area-heuristic splits
  * down to leaves of at most max_leaf_tris (1..8) triangles, two binary levels folded into each 4-wide
- * node, node boxes padded by 2^-18 of the largest coordinate.  pretris: 12 floats per triangle as in
+ * node, child boxes padded by 2^-18 of the largest coordinate and then quantised outwards to 8 bits per plane.  pretris: 12 floats per triangle as in
  * rt_scene_desc.  The result does not depend on `threads` (<= 0: OMP_NUM_THREADS or up to 16 hardware
  * threads).  No counterpart in the reference. */
 typedef struct rt_bvh4 rt_bvh4;

@@ -252,11 +252,11 @@ class Scene:
         return f, ids
 
     def set_bvh4(self, nodes, tri_order):
-        """C oracle only: hand over the product's bounding volume hierarchy (128-byte nodes, triangle order) for the
+        """C oracle only: hand over the product's bounding volume hierarchy (64-byte nodes, triangle order) for the
         restated traversal (intersect(use_bvh=True), render_params(flags=FLAG_ACCEL_BVH))."""
         assert not self.L.is_ref
         nodes = np.ascontiguousarray(nodes)
-        assert nodes.dtype.itemsize == 128
+        assert nodes.dtype.itemsize == 64
         order = np.ascontiguousarray(tri_order, np.uint32)
         f = self.L.lib.orc_scene_set_bvh4
         f.restype = _c.c_int

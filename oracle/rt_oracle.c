@@ -739,17 +739,18 @@ static int visit_node(const traverser* tr, const bsp_node* node, hit_rec* out) {
 /* reference's (line_tri above, src/geometry.hpp:99-132).                                        */
 /* ------------------------------------------------------------------------------------------ */
 
-/* Node layout (rt_bvh4_node, 32 words): lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4] pad[4]. */
+/* Node layout (rt_bvh4_node, 16 words): origin[3], exponents (one byte per axis), qlo.x qlo.y qlo.z qhi.x qhi.y qhi.z
+ * (one word each, byte k = child k), two unused words, child[4].  Plane = origin + q * 2^(exponent-127). */
 int orc_scene_set_bvh4(orc_scene* s, const float* nodes, uint32_t nodeCount, const uint32_t* triOrder, uint32_t triCount) {
     if (!s || !nodes || nodeCount == 0 || triCount != s->triCount) return -1;
     free(s->bvhNodes); free(s->bvhTris); free(s->bvhMesh); free(s->bvhTri); free(s->bvhGlobal);
     s->bvhGlobal = (uint32_t*)malloc(4 * (size_t)(triCount ? triCount : 1));
-    s->bvhNodes = (float*)malloc((size_t)nodeCount * 128);
+    s->bvhNodes = (float*)malloc((size_t)nodeCount * 64);
     s->bvhTris = (pretri*)malloc(sizeof(pretri) * (size_t)(triCount ? triCount : 1));
     s->bvhMesh = (uint32_t*)malloc(4 * (size_t)(triCount ? triCount : 1));
     s->bvhTri = (uint32_t*)malloc(4 * (size_t)(triCount ? triCount : 1));
     if (!s->bvhNodes || !s->bvhTris || !s->bvhMesh || !s->bvhTri || !s->bvhGlobal) return -1;
-    memcpy(s->bvhNodes, nodes, (size_t)nodeCount * 128);
+    memcpy(s->bvhNodes, nodes, (size_t)nodeCount * 64);
     s->bvhNodeCount = nodeCount;
     s->bvhTriCount = triCount;
     for (uint32_t k = 0; k < triCount; ++k) {
@@ -765,11 +766,21 @@ int orc_scene_set_bvh4(orc_scene* s, const float* nodes, uint32_t nodeCount, con
     return 0;
 }
 
-/* Entry parameter of the line into child k's box, +inf when it misses within [lower, upper]. */
+/* Entry parameter of the line into child k's box, +inf when it misses within [lower, upper].  A crossing parameter
+ * is evaluated from the stored byte: t = fma(q, step * r, (origin - o) * r). */
 static inline float bvh_child_entry(v3 o, v3 r, const float* n, int k, float lower, float upper) {
-    float ax = (n[k] - o.x) * r.x, bx = (n[12 + k] - o.x) * r.x;
-    float ay = (n[4 + k] - o.y) * r.y, by = (n[16 + k] - o.y) * r.y;
-    float az = (n[8 + k] - o.z) * r.z, bz = (n[20 + k] - o.z) * r.z;
+    uint32_t w[16];
+    memcpy(w, n, 64);
+    uint32_t e = w[3];
+    float sx, sy, sz;
+    uint32_t bx_ = (e & 0xFFu) << 23, by_ = ((e >> 8) & 0xFFu) << 23, bz_ = ((e >> 16) & 0xFFu) << 23;
+    memcpy(&sx, &bx_, 4); memcpy(&sy, &by_, 4); memcpy(&sz, &bz_, 4);
+    float Ax = sx * r.x, Ay = sy * r.y, Az = sz * r.z;
+    float Bx = (n[0] - o.x) * r.x, By = (n[1] - o.y) * r.y, Bz = (n[2] - o.z) * r.z;
+    int sh = 8 * k;
+    float ax = fmaf((float)((w[4] >> sh) & 0xFFu), Ax, Bx), bx = fmaf((float)((w[7] >> sh) & 0xFFu), Ax, Bx);
+    float ay = fmaf((float)((w[5] >> sh) & 0xFFu), Ay, By), by = fmaf((float)((w[8] >> sh) & 0xFFu), Ay, By);
+    float az = fmaf((float)((w[6] >> sh) & 0xFFu), Az, Bz), bz = fmaf((float)((w[9] >> sh) & 0xFFu), Az, Bz);
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), lower));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), upper));
     return tn <= tf * (1.0f + 0x1p-22f) ? tn : INFINITY;
@@ -780,14 +791,18 @@ static int bvh_nearest_hit(const orc_scene* s, v3 o, v3 d, float tMin, int front
     uint32_t stack[256];
     int sp = 0, found = 0;
     uint32_t cur = 0, bestSlot = 0;
-    v3 r = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    /* reciprocal direction, held within +-2^80 so that an axis-parallel line gets huge finite crossing parameters of
+     * the right sign instead of inf - inf */
+    v3 r = V(fabsf(d.x) < 0x1p-80f ? copysignf(0x1p80f, d.x) : 1.0f / d.x,
+             fabsf(d.y) < 0x1p-80f ? copysignf(0x1p80f, d.y) : 1.0f / d.y,
+             fabsf(d.z) < 0x1p-80f ? copysignf(0x1p80f, d.z) : 1.0f / d.z);
     float lower = fminf(tMin, 0.0f);
     float bestT = INFINITY, bestU = 0.0f, bestV = 0.0f;
     while (cur != NONE) {
         if (!(cur & 0x80000000u)) {
-            const float* n = s->bvhNodes + 32 * (size_t)cur;
+            const float* n = s->bvhNodes + 16 * (size_t)cur;
             uint32_t child[4];
-            memcpy(child, n + 24, 16);
+            memcpy(child, n + 12, 16);
             float t[4];
             int nHit = 0;
             if (st) st->inodeVisits++;

@@ -72,7 +72,7 @@ void orc_scene_destroy(orc_scene*);
  * (src/geometry.hpp:117-132).  Same bits either way; the second is what the CPU baseline times. */
 void orc_scene_set_simd_leaves(orc_scene*, int enable);
 /* The product's alternative accelerator (not in the reference): a 4-wide bounding volume hierarchy as the
- * library's builder lays it out (32 words per node) and the order of the scene's triangles in its leaves.
+ * library's builder lays it out (16 words per node) and the order of the scene's triangles in its leaves.
  * orc_intersect with bit 1 of frontOnly set, and device-mode rendering with ORC_FLAG_ACCEL_BVH, then restate
  * the library's traversal of it.  Returns 0, or -1 on a size mismatch. */
 int orc_scene_set_bvh4(orc_scene*, const float* nodes, uint32_t nodeCount, const uint32_t* triOrder, uint32_t triCount);

@@ -28,12 +28,13 @@ INODE_DTYPE = np.dtype([("neg_box", np.float32, 6), ("neg_index", np.int32), ("p
 TRI_REF_DTYPE = np.dtype([("mesh", np.uint32), ("tri", np.uint32)])
 HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("point", np.float32, 3),
                       ("mesh", np.uint32), ("tri", np.uint32)])
-# rt_bvh4_node: one 128-byte node of the alternative accelerator (include/rt_amd.h)
-BVH4_NODE_DTYPE = np.dtype([("lo_x", np.float32, 4), ("lo_y", np.float32, 4), ("lo_z", np.float32, 4),
-                            ("hi_x", np.float32, 4), ("hi_y", np.float32, 4), ("hi_z", np.float32, 4),
-                            ("child", np.uint32, 4), ("pad_", np.uint32, 4)])
+# rt_bvh4_node: one 64-byte node of the alternative accelerator (include/rt_amd.h)
+BVH4_NODE_DTYPE = np.dtype([("origin", np.float32, 3), ("exp", np.uint8, 3), ("pad0_", np.uint8),
+                            ("qlo_x", np.uint8, 4), ("qlo_y", np.uint8, 4), ("qlo_z", np.uint8, 4),
+                            ("qhi_x", np.uint8, 4), ("qhi_y", np.uint8, 4), ("qhi_z", np.uint8, 4),
+                            ("pad1_", np.uint32, 2), ("child", np.uint32, 4)])
 assert INODE_DTYPE.itemsize == 60 and ctypes.sizeof(RtInode) == 60 and HIT_DTYPE.itemsize == 32
-assert BVH4_NODE_DTYPE.itemsize == 128
+assert BVH4_NODE_DTYPE.itemsize == 64
 
 
 class RtSceneDesc(ctypes.Structure):

@@ -2,7 +2,7 @@
 // preprocessed triangles, built top-down with the binned surface area heuristic.  The reference has one
 // accelerator only, BSPTree (src/bsp.hpp:35-48); this one stands behind the same nearest-intersection
 // query (src/bsp.hpp:50-51) as an option: every triangle is stored once, leaves hold at most a handful of
-// triangles, and a node's four child boxes fill one 128-byte line.
+// triangles, and a node with its four child boxes is one 64-byte record.
 //
 // The build is deterministic: the tree depends only on the triangles and the parameters, not on the number
 // of threads (subtrees are built in parallel, node numbers are assigned afterwards in one sequential pass).
@@ -196,6 +196,51 @@ struct Builder {
 
 }  // namespace
 
+namespace {
+
+// Stores up to four child boxes in a node as 8-bit offsets from the node's lower corner.  Per axis the step is
+// the smallest power of two with 255 steps spanning the children; a lower plane is rounded down and an upper
+// plane up, and each stored plane is checked as the traversal decodes it (RN(origin + q * step)), so the stored
+// box always contains the box it was made from.
+void quantise(rt_bvh4_node& node, const Box* boxes, int count) {
+    Box all;
+    all.reset();
+    for (int k = 0; k < count; ++k) all.grow(boxes[k]);
+    uint8_t* const qlo[3] = {node.qlo_x, node.qlo_y, node.qlo_z};
+    uint8_t* const qhi[3] = {node.qhi_x, node.qhi_y, node.qhi_z};
+    for (int a = 0; a < 3; ++a) {
+        float const origin = all.lo[a];
+        node.origin[a] = origin;
+        double const extent = double(all.hi[a]) - double(origin);
+        int e = 1;                                           // biased exponent of the step
+        if (extent > 0.0) {
+            int ex = 0;
+            (void)std::frexp(extent / 255.0, &ex);           // extent/255 = m * 2^ex, m in [0.5, 1)
+            e = std::min(254, std::max(1, ex + 127));        // step = 2^ex >= extent/255
+        }
+        for (;;) {
+            double const step = std::ldexp(1.0, e - 127);
+            bool fits = true;
+            for (int k = 0; k < count && fits; ++k) {
+                double lo = std::floor((double(boxes[k].lo[a]) - origin) / step);
+                double hi = std::ceil((double(boxes[k].hi[a]) - origin) / step);
+                lo = std::max(0.0, lo);
+                // as decoded by the traversal: float(q) * step is exact, the sum is rounded once
+                while (lo > 0.0 && float(double(origin) + lo * step) > boxes[k].lo[a]) lo -= 1.0;
+                while (hi <= 255.0 && float(double(origin) + hi * step) < boxes[k].hi[a]) hi += 1.0;
+                if (hi > 255.0 || float(double(origin) + lo * step) > boxes[k].lo[a]) { fits = false; break; }
+                qlo[a][k] = uint8_t(lo);
+                qhi[a][k] = uint8_t(hi);
+            }
+            if (fits || e >= 254) break;
+            ++e;
+        }
+        node.exp[a] = uint8_t(e);
+    }
+}
+
+}  // namespace
+
 struct rt_bvh4 {
     std::vector<rt_bvh4_node> nodes;
     std::vector<uint32_t> order;
@@ -260,19 +305,24 @@ int rt_bvh4_build(const float* pretris, uint32_t pretri_count, uint32_t max_leaf
 
         // ---- collapse to four children per node, number the nodes, pad the boxes ------------------------------
         // A node's interior children get consecutive numbers (they are the lines a traversal step may touch next);
-        // subtrees follow depth-first.  Boxes are padded by 2^-18 of the largest coordinate, which covers the
-        // rounding of the slab test and of the corner sums above.
+        // subtrees follow depth-first.  Child boxes are padded by 2^-18 of the largest coordinate, which covers the
+        // rounding of the slab test and of the corner sums above, and then quantised outwards.
         float const pad = absMax * 0x1p-18f;
         struct Item { uint32_t node2, node4, depth; };
         std::vector<Item> todo;
         R->nodes.push_back(empty);
         todo.push_back({0u, 0u, 1u});
         auto leafRef = [&](const Node2& n) { return 0x80000000u | ((n.count - 1u) << 28) | n.first; };
+        auto padded = [&](const Box& b) {
+            Box p = b;
+            for (int k = 0; k < 3; ++k) { p.lo[k] -= pad; p.hi[k] += pad; }
+            return p;
+        };
         if (B.nodes[0].count > 0) {          // the whole scene is one leaf
             rt_bvh4_node& n4 = R->nodes[0];
             const Node2& n = B.nodes[0];
-            n4.lo_x[0] = n.box.lo[0] - pad; n4.lo_y[0] = n.box.lo[1] - pad; n4.lo_z[0] = n.box.lo[2] - pad;
-            n4.hi_x[0] = n.box.hi[0] + pad; n4.hi_y[0] = n.box.hi[1] + pad; n4.hi_z[0] = n.box.hi[2] + pad;
+            Box const only = padded(n.box);
+            quantise(n4, &only, 1);
             n4.child[0] = leafRef(n);
             R->leafCount = 1;
             R->maxLeafFound = n.count;
@@ -307,10 +357,11 @@ int rt_bvh4_build(const float* pretris, uint32_t pretri_count, uint32_t max_leaf
             uint32_t next = firstInterior;
             Item pushed[4];
             int pushedCount = 0;
+            Box childBoxes[4];
+            for (int k = 0; k < n; ++k) childBoxes[k] = padded(B.nodes[kids[k]].box);
+            quantise(n4, childBoxes, n);
             for (int k = 0; k < n; ++k) {
                 const Node2& c = B.nodes[kids[k]];
-                n4.lo_x[k] = c.box.lo[0] - pad; n4.lo_y[k] = c.box.lo[1] - pad; n4.lo_z[k] = c.box.lo[2] - pad;
-                n4.hi_x[k] = c.box.hi[0] + pad; n4.hi_y[k] = c.box.hi[1] + pad; n4.hi_z[k] = c.box.hi[2] + pad;
                 if (c.count > 0) {
                     n4.child[k] = leafRef(c);
                     ++R->leafCount;

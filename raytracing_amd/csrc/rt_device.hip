@@ -493,24 +493,46 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
 }
 
 // ---- alternative accelerator: 4-wide bounding volume hierarchy ----------------------------------------
-// Node record (rt_bvh4_node, 128 bytes = eight float4): child boxes as a structure of arrays
-//   {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]} {child[4]} {unused}
+// Node record (rt_bvh4_node, 64 bytes = four float4):
+//   {origin.x origin.y origin.z exponents} {qlo.x[4] qlo.y[4] qlo.z[4] qhi.x[4]} {qhi.y[4] qhi.z[4] - -} {child[4]}
+// A child's box plane on axis a is origin[a] + q * 2^(exponent[a]-127), q the child's byte of the plane's word.
 // child: 0xFFFFFFFF none; bit 31: leaf, first triangle in bits 0-27, count-1 in bits 28-30; else a node number.
 // Triangle records and ids have the layout of the BSP leaves' (48 and 16 bytes), one per triangle.
 //
-// Entry parameter of the line into one child box, or +inf when it misses the box within [lower, upper]:
-// slab crossing parameters (plane - origin) * RN(1/direction), the far end widened by one part in 2^22 so
-// that rounding cannot lose a box the exact line touches (the boxes are padded as well).  Written with
-// fminf/fmaxf, which return the other operand when one is NaN (0 * inf of an axis-parallel line on a
-// box plane), so such an axis does not constrain the interval.
-__device__ __forceinline__ float childEntry(V3 o, V3 r, float lox, float loy, float loz, float hix, float hiy, float hiz,
-                                            float lower, float upper) {
-    float const ax = (lox - o.x) * r.x, bx = (hix - o.x) * r.x;
-    float const ay = (loy - o.y) * r.y, by = (hiy - o.y) * r.y;
-    float const az = (loz - o.z) * r.z, bz = (hiz - o.z) * r.z;
+// nodeEntries gives, for each child, the entry parameter of the line into the child's box, or +inf when the line
+// misses the box within [lower, upper] or the child does not exist.  A slab crossing parameter is evaluated
+// straight from the stored byte, t = fma(q, step * RN(1/d), (origin - o) * RN(1/d)); the far end of the interval
+// is widened by one part in 2^22 so that rounding cannot lose a box the exact line touches (the boxes are padded
+// as well).  fminf/fmaxf return the other operand when one is NaN, so a NaN never rejects a box.
+struct NodeEntries { float t0, t1, t2, t3; uint32_t c0, c1, c2, c3; };
+
+__device__ __forceinline__ float slabEntry(float ax, float bx, float ay, float by, float az, float bz, float lower, float upper) {
     float const tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), lower));
     float const tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), upper));
     return tn <= tf * (1.0f + 0x1p-22f) ? tn : INFINITY;
+}
+
+__device__ __forceinline__ NodeEntries nodeEntries(const float4* __restrict__ np, V3 o, V3 r, float lower, float upper) {
+    float4 const h = np[0], q1 = np[1], q2 = np[2], cf = np[3];
+    uint32_t const e = __float_as_uint(h.w);
+    float const Ax = __uint_as_float((e & 0xFFu) << 23) * r.x, Ay = __uint_as_float(((e >> 8) & 0xFFu) << 23) * r.y,
+                Az = __uint_as_float(((e >> 16) & 0xFFu) << 23) * r.z;
+    float const Bx = (h.x - o.x) * r.x, By = (h.y - o.y) * r.y, Bz = (h.z - o.z) * r.z;
+    uint32_t const lx = __float_as_uint(q1.x), ly = __float_as_uint(q1.y), lz = __float_as_uint(q1.z),
+                   hx = __float_as_uint(q1.w), hy = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
+    NodeEntries n;
+    n.c0 = __float_as_uint(cf.x); n.c1 = __float_as_uint(cf.y); n.c2 = __float_as_uint(cf.z); n.c3 = __float_as_uint(cf.w);
+#define RT_BVH_CHILD(k)                                                                                             \
+    slabEntry(__fmaf_rn(static_cast<float>((lx >> (8 * (k))) & 0xFFu), Ax, Bx), __fmaf_rn(static_cast<float>((hx >> (8 * (k))) & 0xFFu), Ax, Bx), \
+              __fmaf_rn(static_cast<float>((ly >> (8 * (k))) & 0xFFu), Ay, By), __fmaf_rn(static_cast<float>((hy >> (8 * (k))) & 0xFFu), Ay, By), \
+              __fmaf_rn(static_cast<float>((lz >> (8 * (k))) & 0xFFu), Az, Bz), __fmaf_rn(static_cast<float>((hz >> (8 * (k))) & 0xFFu), Az, Bz), \
+              lower, upper)
+    n.t0 = n.c0 == 0xFFFFFFFFu ? INFINITY : RT_BVH_CHILD(0);
+    n.t1 = n.c1 == 0xFFFFFFFFu ? INFINITY : RT_BVH_CHILD(1);
+    n.t2 = n.c2 == 0xFFFFFFFFu ? INFINITY : RT_BVH_CHILD(2);
+    n.t3 = n.c3 == 0xFFFFFFFFu ? INFINITY : RT_BVH_CHILD(3);
+#undef RT_BVH_CHILD
+    return n;
 }
 
 // Nearest accepted triangle over the whole scene for a stream of n lines, one lane per line: the query of
@@ -571,7 +593,13 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             if (!active && rank < avail) {
                 line = chunkNext + rank;
                 load(line, o, d);
-                r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                // Reciprocal direction, held within +-2^80: an axis-parallel line then gets huge finite crossing
+                // parameters of the right sign on that axis (its slab either contains the whole line or none of it)
+                // instead of inf - inf, which would leave the axis unconstrained and send the line through every box
+                // of its column.
+                r = mk(fabsf(d.x) < 0x1p-80f ? copysignf(0x1p80f, d.x) : 1.0f / d.x,
+                       fabsf(d.y) < 0x1p-80f ? copysignf(0x1p80f, d.y) : 1.0f / d.y,
+                       fabsf(d.z) < 0x1p-80f ? copysignf(0x1p80f, d.z) : 1.0f / d.z);
                 sp = 0; cur = 0;
                 triPos = 0; triEnd = 0;
                 best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
@@ -595,20 +623,10 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             ta = tp[0]; tb = tp[1]; te = tp[2];
         }
         else {
-            float4 const* np = S.nodes + 8 * static_cast<size_t>(cur);
-            float4 const lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-            float4 const cf = np[6];
-            uint32_t const c0 = __float_as_uint(cf.x), c1 = __float_as_uint(cf.y), c2 = __float_as_uint(cf.z),
-                           c3 = __float_as_uint(cf.w);
+            NodeEntries const ne = nodeEntries(S.nodes + 4 * static_cast<size_t>(cur), o, r, lower, best.t);
+            uint32_t const c0 = ne.c0, c1 = ne.c1, c2 = ne.c2, c3 = ne.c3;
+            float const t0 = ne.t0, t1 = ne.t1, t2 = ne.t2, t3 = ne.t3;
             if (COUNT) { c.inodeVisits++; c.boxTests += (c0 != NONE) + (c1 != NONE) + (c2 != NONE) + (c3 != NONE); }
-            float t0 = childEntry(o, r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, lower, best.t);
-            float t1 = childEntry(o, r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, lower, best.t);
-            float t2 = childEntry(o, r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, lower, best.t);
-            float t3 = childEntry(o, r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, lower, best.t);
-            if (c0 == NONE) t0 = INFINITY;
-            if (c1 == NONE) t1 = INFINITY;
-            if (c2 == NONE) t2 = INFINITY;
-            if (c3 == NONE) t3 = INFINITY;
             int const nHit = (t0 < INFINITY) + (t1 < INFINITY) + (t2 < INFINITY) + (t3 < INFINITY);
             if (nHit == 0) {
                 if (sp > 0) {
@@ -691,20 +709,10 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
         else {
         // ---- phase 1: interior nodes until the lane stands on a leaf or has nothing left ------------
         while ((cur & 0x80000000u) == 0u) {
-            float4 const* np = S.nodes + 8 * static_cast<size_t>(cur);
-            float4 const lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-            float4 const cf = np[6];
-            uint32_t const c0 = __float_as_uint(cf.x), c1 = __float_as_uint(cf.y), c2 = __float_as_uint(cf.z),
-                           c3 = __float_as_uint(cf.w);
+            NodeEntries const ne = nodeEntries(S.nodes + 4 * static_cast<size_t>(cur), o, r, lower, best.t);
+            uint32_t const c0 = ne.c0, c1 = ne.c1, c2 = ne.c2, c3 = ne.c3;
+            float const t0 = ne.t0, t1 = ne.t1, t2 = ne.t2, t3 = ne.t3;
             if (COUNT) { c.inodeVisits++; c.boxTests += (c0 != NONE) + (c1 != NONE) + (c2 != NONE) + (c3 != NONE); }
-            float t0 = childEntry(o, r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, lower, best.t);
-            float t1 = childEntry(o, r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, lower, best.t);
-            float t2 = childEntry(o, r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, lower, best.t);
-            float t3 = childEntry(o, r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, lower, best.t);
-            if (c0 == NONE) t0 = INFINITY;
-            if (c1 == NONE) t1 = INFINITY;
-            if (c2 == NONE) t2 = INFINITY;
-            if (c3 == NONE) t3 = INFINITY;
             int const nHit = (t0 < INFINITY) + (t1 < INFINITY) + (t2 < INFINITY) + (t3 < INFINITY);
             if (nHit == 0) {
                 if (sp > 0) {
@@ -1886,7 +1894,7 @@ int checkRenderParams(const rt_scene* s, const rt_render_params* p, const float*
 extern "C" {
 
 const char* rt_last_error(void) { return g_lastError.c_str(); }
-uint32_t rt_abi_version(void) { return 6; }
+uint32_t rt_abi_version(void) { return 7; }
 
 int rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     return guarded("rt_scene_create", [&] { return sceneCreate(D, device, out); });

@@ -85,7 +85,7 @@ class Bvh4:
              self.largest_leaf) = [int(x) for x in counts]
             pn, po = _lib.vp(), _lib.vp()
             L.rt_bvh4_view(h, ctypes.byref(pn), ctypes.byref(po))
-            raw = ctypes.string_at(pn.value, 128 * self.node_count)
+            raw = ctypes.string_at(pn.value, 64 * self.node_count)
             self.nodes = np.frombuffer(raw, _lib.BVH4_NODE_DTYPE).copy()
             if self.tri_count:
                 self.tri_order = np.frombuffer(ctypes.string_at(po.value, 4 * self.tri_count), np.uint32).copy()

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported():
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.RtInode) == 60
     assert _lib.HIT_DTYPE.itemsize == 32 and _lib.TRI_REF_DTYPE.itemsize == 8
-    assert _lib.lib().rt_abi_version() == 6
+    assert _lib.lib().rt_abi_version() == 7
 
 
 def test_errors_are_reported_not_crashed():

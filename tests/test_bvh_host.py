@@ -23,10 +23,16 @@ def check_structure(b, pretris):
     nodes, order = b.nodes, b.tri_order
     assert sorted(order.tolist()) == list(range(len(pretris)))
     pts = corners(pretris)[order]                                             # hierarchy order
-    lo = np.stack([nodes["lo_x"], nodes["lo_y"], nodes["lo_z"]], -1)          # [node, child, xyz]
-    hi = np.stack([nodes["hi_x"], nodes["hi_y"], nodes["hi_z"]], -1)
+    # planes as stored: origin + q * 2^(exp - 127), the product exact, the sum rounded once to float32
+    step = np.ldexp(1.0, nodes["exp"].astype(np.int64) - 127)                 # [node, xyz] float64
+    origin = nodes["origin"].astype(np.float64)
+    qlo = np.stack([nodes["qlo_x"], nodes["qlo_y"], nodes["qlo_z"]], -1).astype(np.float64)   # [node, child, xyz]
+    qhi = np.stack([nodes["qhi_x"], nodes["qhi_y"], nodes["qhi_z"]], -1).astype(np.float64)
+    lo = (origin[:, None, :] + qlo * step[:, None, :]).astype(np.float32)
+    hi = (origin[:, None, :] + qhi * step[:, None, :]).astype(np.float32)
     covered = np.zeros(len(pretris), np.int32)
-    # bounds of every node's subtree, children before parents (child numbers are larger than the parent's)
+    # bounds of the triangles below every node, children before parents (child numbers are larger than the parent's):
+    # a stored box must contain the triangles of its subtree (it need not contain the outward-rounded boxes stored below)
     sub_lo = np.full((len(nodes), 3), np.inf, np.float32)
     sub_hi = np.full((len(nodes), 3), -np.inf, np.float32)
     leaves = 0
@@ -44,8 +50,8 @@ def check_structure(b, pretris):
                 assert i < c < len(nodes)
                 clo, chi = sub_lo[c], sub_hi[c]
             assert (lo[i, k] <= clo).all() and (hi[i, k] >= chi).all(), (i, k)
-            sub_lo[i] = np.minimum(sub_lo[i], lo[i, k])
-            sub_hi[i] = np.maximum(sub_hi[i], hi[i, k])
+            sub_lo[i] = np.minimum(sub_lo[i], clo)
+            sub_hi[i] = np.maximum(sub_hi[i], chi)
     assert (covered == 1).all()
     assert leaves == b.leaf_count
 
@@ -154,5 +160,37 @@ def test_front_and_back_surfaces(cornell):
             assert np.array_equal(ib, ic) and np.array_equal(fb.view(np.uint32), fc.view(np.uint32))
             same = (ia == ib).all(1) & (fa.view(np.uint32) == fb.view(np.uint32)).all(1)
             assert same.mean() > 0.999
+    finally:
+        osc.close()
+
+
+def axis_parallel_rays(rng, n, lo=-4.5, hi=4.5):
+    """Lines with one or two direction components exactly zero (their reciprocal is infinite)."""
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    o[:, 1] = rng.uniform(0.1, 9.5, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    kind = rng.integers(0, 6, n)
+    for a in range(3):
+        d[kind == a, a] = 0.0                           # one zero component
+        d[kind == 3 + a, (a + 1) % 3] = 0.0             # two zero components
+        d[kind == 3 + a, (a + 2) % 3] = -0.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+def test_axis_parallel_lines(cornell):
+    """A zero direction component must not switch that axis off: the answer stays the brute-force one and the
+    number of nodes visited stays that of an ordinary line."""
+    sc, pt = cornell
+    osc = binding.oracle().scene_create_with_tree(base_from_scene(sc), 64, 64, sc.bsp_tree)
+    try:
+        b = render.Bvh4(pt, 4)
+        osc.set_bvh4(b.nodes, b.tri_order)
+        o, d = axis_parallel_rays(np.random.default_rng(17), 3000)
+        for front in (True, False):
+            fb, ib = osc.intersect(o, d, front_only=front, use_bvh=True)
+            fc, ic = osc.intersect_brute(o, d, front_only=front)
+            assert np.array_equal(ib, ic) and np.array_equal(fb.view(np.uint32), fc.view(np.uint32))
+            assert (ib[:, 0] != NONE).mean() > 0.3
     finally:
         osc.close()

@@ -76,6 +76,23 @@ def test_hits_equal_restated_traversal_brute_force_and_bsp(oracle_lib, monkeypat
         ds.close(); osc.close()
 
 
+def test_axis_parallel_lines_on_the_device(oracle_lib):
+    """Direction components that are exactly zero: same answer as the restatement and as the scan of all triangles."""
+    from test_bvh_host import axis_parallel_rays
+    sc = scenes.cornell_scene()
+    ds, osc, _ = _with_bvh(oracle_lib, sc, 64, 64)
+    try:
+        o, d = axis_parallel_rays(np.random.default_rng(23), 5000)
+        for front in (True, False):
+            got = ds.intersect(o, d, 1e-3, front, use_bvh=True)
+            f, ids = osc.intersect(o, d, 1e-3, front, use_bvh=True)
+            _check_hits(got, f, ids)
+            fb, idb = osc.intersect_brute(o, d, 1e-3, front)
+            _check_hits(got, fb, idb)
+    finally:
+        ds.close(); osc.close()
+
+
 def _assert_same_image_and_work(img, st, oimg, ost):
     assert same_bits(img, oimg), f"{(img != oimg).sum()} of {img.size} values differ"
     assert st["segments"] == ost["segments"] and st["paths"] == ost["paths"] and st["shaded_hits"] == ost["shadedHits"]
