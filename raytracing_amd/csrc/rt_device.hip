@@ -27,6 +27,9 @@
 #define RT_STACK_MAX 64          // per-lane traversal stack entries (tree depth bound)
 #define RT_BLOCK 256
 #define RT_STAGE 256u                // survivors staged per wave before one append to the next queue
+#ifndef RT_BVH_LDS_STACK
+#define RT_BVH_LDS_STACK 20       // the same for the traversal of the bounding volume hierarchy
+#endif
 #define RT_LDS_STACK_DEPTH 20   // traversal stack entries kept in LDS (20 KiB per block: eight blocks fill a CU's 160 KiB); deeper ones spill to scratch
 
 namespace {
@@ -549,8 +552,8 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t const lane = threadIdx.x & 63u;
     unsigned long long const below = (1ull << lane) - 1ull;
-    __shared__ uint32_t ldsStackBvh[RT_LDS_STACK_DEPTH * RT_BLOCK];
-    uint32_t spillStack[SPILL ? RT_STACK_MAX - RT_LDS_STACK_DEPTH : 1];
+    __shared__ uint32_t ldsStackBvh[RT_BVH_LDS_STACK * RT_BLOCK];
+    uint32_t spillStack[SPILL ? RT_STACK_MAX - RT_BVH_LDS_STACK : 1];
     uint32_t* const stack = ldsStackBvh + threadIdx.x;
     uint32_t const waves = gridDim.x * (RT_BLOCK / 64u);
     uint32_t const xcdBlocks = gridDim.x / 8u;
@@ -631,8 +634,8 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             if (nHit == 0) {
                 if (sp > 0) {
                     --sp;
-                    cur = stack[(SPILL ? min(sp, RT_LDS_STACK_DEPTH - 1) : sp) * RT_BLOCK];
-                    if (SPILL && sp >= RT_LDS_STACK_DEPTH) cur = spillStack[sp - RT_LDS_STACK_DEPTH];
+                    cur = stack[(SPILL ? min(sp, RT_BVH_LDS_STACK - 1) : sp) * RT_BLOCK];
+                    if (SPILL && sp >= RT_BVH_LDS_STACK) cur = spillStack[sp - RT_BVH_LDS_STACK];
                 }
                 else cur = NONE;
             }
@@ -646,8 +649,8 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
 #define RT_BVH_DEFER(k, child)                                                                            \
                 if ((k) >= 1 && (k) < nHit) {                                                              \
                     int const pos = sp + nHit - 1 - (k);                                                   \
-                    if (!SPILL || pos < RT_LDS_STACK_DEPTH) stack[pos * RT_BLOCK] = (child);               \
-                    else spillStack[pos - RT_LDS_STACK_DEPTH] = (child);                                   \
+                    if (!SPILL || pos < RT_BVH_LDS_STACK) stack[pos * RT_BLOCK] = (child);               \
+                    else spillStack[pos - RT_BVH_LDS_STACK] = (child);                                   \
                 }
                 RT_BVH_DEFER(k0, c0)
                 RT_BVH_DEFER(k1, c1)
@@ -688,8 +691,8 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             if (triPos == triEnd) {                     // leaf finished: next deferred child
                 if (sp > 0) {
                     --sp;
-                    cur = stack[(SPILL ? min(sp, RT_LDS_STACK_DEPTH - 1) : sp) * RT_BLOCK];
-                    if (SPILL && sp >= RT_LDS_STACK_DEPTH) cur = spillStack[sp - RT_LDS_STACK_DEPTH];
+                    cur = stack[(SPILL ? min(sp, RT_BVH_LDS_STACK - 1) : sp) * RT_BLOCK];
+                    if (SPILL && sp >= RT_BVH_LDS_STACK) cur = spillStack[sp - RT_BVH_LDS_STACK];
                 }
                 else cur = NONE;
             }
@@ -717,8 +720,8 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             if (nHit == 0) {
                 if (sp > 0) {
                     --sp;
-                    cur = stack[(SPILL ? min(sp, RT_LDS_STACK_DEPTH - 1) : sp) * RT_BLOCK];
-                    if (SPILL && sp >= RT_LDS_STACK_DEPTH) cur = spillStack[sp - RT_LDS_STACK_DEPTH];
+                    cur = stack[(SPILL ? min(sp, RT_BVH_LDS_STACK - 1) : sp) * RT_BLOCK];
+                    if (SPILL && sp >= RT_BVH_LDS_STACK) cur = spillStack[sp - RT_BVH_LDS_STACK];
                 }
                 else cur = NONE;
                 continue;
@@ -732,8 +735,8 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
 #define RT_BVH_DEFER(k, child)                                                                            \
             if ((k) >= 1 && (k) < nHit) {                                                                  \
                 int const pos = sp + nHit - 1 - (k);                                                       \
-                if (!SPILL || pos < RT_LDS_STACK_DEPTH) stack[pos * RT_BLOCK] = (child);                   \
-                else spillStack[pos - RT_LDS_STACK_DEPTH] = (child);                                       \
+                if (!SPILL || pos < RT_BVH_LDS_STACK) stack[pos * RT_BLOCK] = (child);                   \
+                else spillStack[pos - RT_BVH_LDS_STACK] = (child);                                       \
             }
             RT_BVH_DEFER(k0, c0)
             RT_BVH_DEFER(k1, c1)
@@ -782,8 +785,8 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             }
             if (sp > 0) {
                 --sp;
-                cur = stack[(SPILL ? min(sp, RT_LDS_STACK_DEPTH - 1) : sp) * RT_BLOCK];
-                if (SPILL && sp >= RT_LDS_STACK_DEPTH) cur = spillStack[sp - RT_LDS_STACK_DEPTH];
+                cur = stack[(SPILL ? min(sp, RT_BVH_LDS_STACK - 1) : sp) * RT_BLOCK];
+                if (SPILL && sp >= RT_BVH_LDS_STACK) cur = spillStack[sp - RT_BVH_LDS_STACK];
             }
             else cur = NONE;
         }
@@ -1794,7 +1797,7 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
     uint32_t slotGroup = 1u;
     if (const char* text = std::getenv("RT_AMD_SLOT_GROUP")) slotGroup = static_cast<uint32_t>(std::max(1, std::atoi(text)));
     bool const bvh = (p->flags & RT_FLAG_ACCEL_BVH) != 0;
-    bool const spill = bvh ? s->bvhStackNeed > RT_LDS_STACK_DEPTH : s->depth > RT_LDS_STACK_DEPTH;
+    bool const spill = bvh ? s->bvhStackNeed > RT_BVH_LDS_STACK : s->depth > RT_LDS_STACK_DEPTH;
     int const traceCap = (bvh ? s->gridTraceBvh : s->gridTrace)[countWork ? 1 : 0][spill ? 1 : 0];
     DevScene const& dev = bvh ? s->devBvh : s->dev;
     for (uint32_t done = 0; done < p->spp; done += spb) {
@@ -1959,7 +1962,7 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
     bool const bvh = (front_only & RT_INTERSECT_BVH) != 0;
     bool const front = (front_only & ~RT_INTERSECT_BVH) != 0;
     if (bvh && !s->hasBvh) return fail(RT_ERR_INVALID, "rt_intersect: RT_INTERSECT_BVH without a hierarchy attached (rt_scene_attach_bvh4)");
-    bool const spill = bvh ? s->bvhStackNeed > RT_LDS_STACK_DEPTH : s->depth > RT_LDS_STACK_DEPTH;
+    bool const spill = bvh ? s->bvhStackNeed > RT_BVH_LDS_STACK : s->depth > RT_LDS_STACK_DEPTH;
     int const cap = (bvh ? s->gridIntersectBvh : s->gridIntersect)[front ? 1 : 0][spill ? 1 : 0];
     DevScene const& dev = bvh ? s->devBvh : s->dev;
     for (uint64_t done = 0; done < n; done += slice) {
