@@ -57,10 +57,20 @@ double seconds(std::chrono::steady_clock::time_point a, std::chrono::steady_cloc
 
 }  // namespace
 
-int main(int argc, char** argv) {
+int main(int argcAll, char** argvAll) {
+    // "--bvh" anywhere on the command line: render through the alternative accelerator (RT_FLAG_ACCEL_BVH)
+    std::vector<char*> args;
+    bool hierarchy = false;
+    for (int i = 0; i < argcAll; ++i) {
+        if (i > 0 && std::string(argvAll[i]) == "--bvh") hierarchy = true;
+        else args.push_back(argvAll[i]);
+    }
+    int const argc = static_cast<int>(args.size());
+    char** const argv = args.data();
     unsigned const width = argc > 1 ? std::strtoul(argv[1], nullptr, 10) : 1920;
     unsigned const height = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 1080;
     rt::RenderOptions options;
+    options.boundingVolumeHierarchy = hierarchy;
     if (argc > 3) options.pixelSampleRate = std::strtoul(argv[3], nullptr, 10);
     if (argc > 4) options.seed = std::strtoull(argv[4], nullptr, 10);
     std::string const output = argc > 5 ? argv[5] : "output.ppm";

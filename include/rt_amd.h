@@ -115,9 +115,11 @@ typedef struct {
 #define RT_FLAG_RUSSIAN_ROULETTE 4u
 /* Answer the path loop's nearest-intersection queries (src/render.hpp:104) from the bounding volume
  * hierarchy attached with rt_scene_attach_bvh4 instead of the BSP tree.  Same triangle test, bit for bit
- * (src/geometry.hpp:99-132); the nearest accepted triangle over the whole scene is returned, without the
- * BSP leaf's in-box rule (src/bsp.hpp:82-87), so the two accelerators can differ on rays that graze a
- * triangle edge-on or hit exactly on a leaf boundary.  The converged image is unchanged. */
+ * (src/geometry.hpp:99-132); the answer is the nearest accepted triangle of the whole scene whose hit point
+ * lies in the root box (ties: lowest triangle index).  Of the BSP leaf's in-box rule (src/bsp.hpp:82-87) only
+ * the root box is left, so the two accelerators can differ on a ray whose hit point rounds to just outside an
+ * inner leaf's box and inside no other leaf that holds the triangle: none in 469 000 rays of the built-in
+ * scene, a few in 100 000 on large meshes.  The converged image is unchanged. */
 #define RT_FLAG_ACCEL_BVH 8u
 /* For the front_only argument of rt_intersect / rt_intersect_device: bit 0 = front faces only
  * (Surfaces::FRONT_ONLY, src/geometry.hpp:95-97), bit 1 = use the attached bounding volume hierarchy. */

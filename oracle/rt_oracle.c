@@ -766,6 +766,14 @@ int orc_scene_set_bvh4(orc_scene* s, const float* nodes, uint32_t nodeCount, con
     return 0;
 }
 
+/* What is left of the leaf's in-box rule (src/bsp.hpp:82-87) without leaves: the hit point (Line::operator(),
+ * src/geometry.hpp:30-32) must lie in the root box, bounds included. */
+static inline int inside_root(const orc_scene* s, v3 o, v3 d, float t) {
+    v3 p = V(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+    const box3* b = &s->root.box;
+    return p.x >= b->min.x && p.x <= b->max.x && p.y >= b->min.y && p.y <= b->max.y && p.z >= b->min.z && p.z <= b->max.z;
+}
+
 /* Entry parameter of the line into child k's box, +inf when it misses within [lower, upper].  A crossing parameter
  * is evaluated from the stored byte: t = fma(q, step * r, (origin - o) * r). */
 static inline float bvh_child_entry(v3 o, v3 r, const float* n, int k, float lower, float upper) {
@@ -832,6 +840,7 @@ static int bvh_nearest_hit(const orc_scene* s, v3 o, v3 d, float tMin, int front
             for (uint32_t j = 0; j < count; ++j) {
                 float t, u, v;
                 if (!line_tri(&s->bvhTris[first + j], o, d, frontOnly, &t, &u, &v) || !(t >= tMin)) continue;
+                if (!inside_root(s, o, d, t)) continue;
                 /* equal t: the lower scene-wide triangle index wins */
                 if (t < bestT || (t == bestT && found && s->bvhGlobal[first + j] < s->bvhGlobal[bestSlot])) {
                     bestT = t; bestU = u; bestV = v; bestSlot = first + j; found = 1;
@@ -856,7 +865,8 @@ static int nearest_hit(const orc_scene* s, v3 o, v3 d, float tMin, int frontOnly
 }
 
 /* Nearest triangle the reference's test accepts (src/geometry.hpp:99-132) with t >= tMin, by scanning every
- * triangle of the scene; among equal t the lowest scene-wide index.  No accelerator at all: the yardstick for
+ * triangle of the scene; the hit point must lie in the root box (inside_root); among equal t the lowest scene-wide
+ * index.  No accelerator at all: the yardstick for
  * the alternative accelerator, whose answer must be this one. */
 void orc_intersect_brute(const orc_scene* s, const float* origins, const float* directions, size_t n, float tMin,
                          int frontOnly, float* outFloats, uint32_t* outIds) {
@@ -867,7 +877,7 @@ void orc_intersect_brute(const orc_scene* s, const float* origins, const float* 
         uint32_t best = 0xFFFFFFFFu;
         for (uint32_t g = 0; g < s->triCount; ++g) {
             float t, u, v;
-            if (line_tri(&s->pretris[g], o, d, frontOnly & 1, &t, &u, &v) && t >= tMin && t < bestT) {
+            if (line_tri(&s->pretris[g], o, d, frontOnly & 1, &t, &u, &v) && t >= tMin && t < bestT && inside_root(s, o, d, t)) {
                 bestT = t; bestU = u; bestV = v; best = g;
             }
         }

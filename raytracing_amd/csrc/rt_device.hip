@@ -71,6 +71,7 @@ struct DevScene {
     const float4* triNormals;
     const float4* materials;
     float boxAbsMax;       // largest |coordinate| of the root box: see filterMargin
+    float rootLo[3], rootHi[3];     // the root box (BSPTree::_root.box), used by the hierarchy traversal
 };
 
 struct Counters {
@@ -509,6 +510,15 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
 // as well).  fminf/fmaxf return the other operand when one is NaN, so a NaN never rejects a box.
 struct NodeEntries { float t0, t1, t2, t3; uint32_t c0, c1, c2, c3; };
 
+// What is left of the BSP leaf's in-box rule (src/bsp.hpp:82-87) when there are no leaves: the hit point, evaluated as
+// Line::operator() does (src/geometry.hpp:30-32), must lie in the scene's root box, bounds included.  The reference
+// drops hits on geometry that lies exactly on a face of the root box when the point rounds to just outside it (the
+// built-in scene's floor at y = 0: 1.5 % of the rays that go down to it); with this test the hierarchy drops them too.
+__device__ __forceinline__ bool insideRoot(const DevScene& S, V3 o, V3 d, float t) {
+    float const px = o.x + t * d.x, py = o.y + t * d.y, pz = o.z + t * d.z;
+    return px >= S.rootLo[0] && px <= S.rootHi[0] && py >= S.rootLo[1] && py <= S.rootHi[1] && pz >= S.rootLo[2] && pz <= S.rootHi[2];
+}
+
 __device__ __forceinline__ float slabEntry(float ax, float bx, float ay, float by, float az, float bz, float lower, float upper) {
     float const tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), lower));
     float const tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), upper));
@@ -540,7 +550,8 @@ __device__ __forceinline__ NodeEntries nodeEntries(const float4* __restrict__ np
 
 // Nearest accepted triangle over the whole scene for a stream of n lines, one lane per line: the query of
 // src/bsp.hpp:50-51 answered from the hierarchy.  Each triangle is tested with the reference's arithmetic
-// (src/geometry.hpp:99-132) and accepted when t >= tMin and t < the best so far; among equal t the triangle
+// (src/geometry.hpp:99-132) and accepted when t >= tMin, the hit point lies in the root box (insideRoot) and t < the
+// best so far; among equal t the triangle
 // with the lowest scene-wide index wins (the order of a BSP leaf's scan, src/bsp.hpp:73-97), so the answer
 // does not depend on the visiting order.  Children are visited nearest entry first (ties: lower slot first), the
 // others are deferred on the per-lane stack farthest first; a child whose entry lies beyond the best hit
@@ -684,7 +695,8 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
                 // equal t (coplanar, overlapping triangles): the lower scene-wide triangle index wins, which makes
                 // the result independent of the order in which leaves are visited
                 if (u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f && t >= tMin
-                    && (t < best.t || (t == best.t && best.ref != NONE && S.leafIds[slot].z < S.leafIds[best.ref].z))) {
+                    && (t < best.t || (t == best.t && best.ref != NONE && S.leafIds[slot].z < S.leafIds[best.ref].z))
+                    && insideRoot(S, o, d, t)) {
                     best.t = t; best.u = u; best.v = v; best.ref = slot;
                 }
             }
@@ -779,7 +791,8 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
                 if (!(t >= tMin)) continue;
                 // equal t (coplanar, overlapping triangles): the lower scene-wide triangle index wins, which makes the
                 // result independent of the order in which leaves are visited
-                if (t < best.t || (t == best.t && best.ref != NONE && S.leafIds[first + j].z < S.leafIds[best.ref].z)) {
+                if ((t < best.t || (t == best.t && best.ref != NONE && S.leafIds[first + j].z < S.leafIds[best.ref].z))
+                    && insideRoot(S, o, d, t)) {
                     best.t = t; best.u = u; best.v = v; best.ref = first + j;
                 }
             }
@@ -1601,6 +1614,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     s->dev.triNormals = static_cast<const float4*>(s->dTriNormals);
     s->dev.materials = static_cast<const float4*>(s->dMaterials);
     s->dev.boxAbsMax = 0.0f;
+    for (int k = 0; k < 3; ++k) { s->dev.rootLo[k] = nodes[0].lo[k]; s->dev.rootHi[k] = nodes[0].hi[k]; }
     for (int k = 0; k < 3; ++k)
         s->dev.boxAbsMax = std::max(s->dev.boxAbsMax, std::max(std::fabs(nodes[0].lo[k]), std::fabs(nodes[0].hi[k])));
     s->nodeCount = static_cast<uint32_t>(nodes.size());

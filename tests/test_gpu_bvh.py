@@ -2,8 +2,9 @@
 hierarchy behind the same nearest-intersection query.  The reference has no such accelerator; what is checked:
   * the GPU traversal equals the oracle's restatement of it bit for bit (hits, rendered radiance, work counters);
   * its answer is the nearest triangle the reference's triangle test accepts (src/geometry.hpp:99-132): bit-equal
-    to a scan of all triangles, and bit-equal to the BSP path (src/bsp.hpp:50-145) on all but a few rays in a
-    hundred thousand (the BSP's in-leaf-box rule, src/bsp.hpp:82-87, can drop a hit; the hierarchy cannot);
+    to a scan of all triangles (hit point inside the root box, ties to the lowest triangle index), and bit-equal to
+    the BSP path (src/bsp.hpp:50-145) on all but a few rays in a hundred thousand (of the BSP's in-leaf-box rule,
+    src/bsp.hpp:82-87, the hierarchy keeps only the root box);
   * rendering through it converges to the reference's image inside the same 1/sqrt(n) envelope as the BSP path."""
 import numpy as np
 import pytest

@@ -698,6 +698,13 @@ def test_cpp_host_layer_program_matches_python_path(tmp_path):
     assert other.std() > 10 and not np.array_equal(other, theirs)
     run = subprocess.run([exe, "480", "270", "4", "11", str(out2), str(tmp_path / "missing.obj")], capture_output=True, text=True, timeout=60)
     assert run.returncode == 1 and "cannot read" in run.stderr
+    # the same frame through the alternative accelerator (rt::RenderOptions::boundingVolumeHierarchy): the same picture
+    # up to the few paths whose nearest hit differs
+    out3 = tmp_path / "bvh.ppm"
+    run = subprocess.run([exe, "480", "270", "4", "11", str(out3), "--bvh"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    through = np.frombuffer(out3.read_bytes(), np.uint8, offset=len(header)).reshape(270, 480, 3)
+    assert (through != theirs).any(-1).mean() < 0.01
 
 
 def test_bench_two_rank_rehearsal_on_one_gpu():
