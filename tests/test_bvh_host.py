@@ -194,3 +194,38 @@ def test_axis_parallel_lines(cornell):
             assert (ib[:, 0] != NONE).mean() > 0.3
     finally:
         osc.close()
+
+
+def test_built_in_scene_hits_equal_the_bsp_traversal():
+    """The reference's own scene (src/main.cpp:134-187): its floor lies exactly on the lower face of the root box, and
+    the BSP traversal drops the hits whose point rounds to just below it (1.5 % of the rays that go down to the floor).
+    The hierarchy keeps the root-box part of the in-box rule (src/bsp.hpp:82-87), so it drops them too: every one of
+    these rays gets the same answer from both accelerators."""
+    sc = scenes.builtin_scene(3).preprocess()
+    w, h = 480, 270
+    osc = binding.oracle().scene_create_with_tree(base_from_scene(sc), w, h, sc.bsp_tree)
+    try:
+        b = render.Bvh4(sc.preprocessed_tris.tris, 4)
+        osc.set_bvh4(b.nodes, b.tri_order)
+        rng = np.random.default_rng(1)
+        xy = np.stack([rng.uniform(0, w, 60000), rng.uniform(0, h, 60000)], 1).astype(np.float32)
+        d = osc.camera_rays(xy)
+        o = np.tile(np.asarray(sc.camera.position, np.float32), (len(d), 1))
+        dropped = 0
+        for generation in range(3):
+            fa, ia = osc.intersect(o, d)
+            fb, ib = osc.intersect(o, d, use_bvh=True)
+            assert np.array_equal(ia, ib) and np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+            if generation:
+                # rays that end on the floor plane but get no hit: the reference's dropped hits are really there
+                t_floor = -o[:, 1] / np.where(d[:, 1] < 0, d[:, 1], -1e-30)
+                p = o + t_floor[:, None] * d
+                on_floor = (d[:, 1] < 0) & (np.abs(p[:, 0] - 2) < 7.9) & (np.abs(p[:, 2] - 2) < 7.9)
+                dropped += int((on_floor & (ia[:, 0] == NONE)).sum())
+            hit = ib[:, 0] != NONE
+            o = fb[hit, 3:6].copy()
+            d = rng.normal(size=o.shape).astype(np.float32)
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+        assert dropped > 100
+    finally:
+        osc.close()
