@@ -246,3 +246,64 @@ def test_dragon_scale_scene_through_the_hierarchy(oracle_lib, dragon_inputs, mon
         print("segments bvh/bsp", sf["segments"], sb["segments"])
     finally:
         ds.close(); osc.close()
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, (0, 0, 0)), (1e-3, (0, 0, 0)), (0.05, (0, 0, 0)), (3e3, (0, 0, 0)),
+                                          (1.0, (500, -200, 1000)), (0.02, (7, 7, 7))])
+def test_random_soups_at_many_scales(oracle_lib, scale, offset):
+    """Random triangle soups from millimetres to kilometres and far from the origin: the padding of the stored boxes
+    and the widening of the slab interval scale with the coordinates, so the hierarchy must still return exactly what
+    a scan of all triangles returns (any box lost to rounding would show up as a missing hit), for lines that start
+    inside and outside the scene."""
+    from raytracing_amd import scene as S
+    rng = np.random.default_rng(int(scale * 1000) + int(offset[0]))
+    n = 2500
+    centres = rng.uniform(-4, 4, (n, 1, 3))
+    pos = ((centres + rng.uniform(-0.3, 0.3, (n, 3, 3))).reshape(-1, 3) * scale).astype(np.float32)
+    nrm = rng.standard_normal((len(pos), 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    tris = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    m = S.Models()
+    off = np.array(offset, np.float64) * scale
+    m.add(S.MeshTransform(tuple(off), S.IDENTITY_QUAT, (1, 1, 1)), 0, 0)
+    m.add(S.MeshTransform(tuple(off + np.array([0.3, 0.1, -0.2]) * scale), (0.2, 0.4, 0.1), (1.0, 0.7, 1.2)), 0, 1)
+    cam = S.Camera(tuple(off + np.array([0, 0, 14.0]) * scale), (0, np.pi, 0), 0.7)
+    mats = [S.Material((0.6, 0.5, 0.4), 0.4, 0.2, (0.5, 0.4, 0.3)), S.Material((0.9, 0.9, 0.9), 0.1, 0.9)]
+    sc = S.Scene(cam, S.Meshes([(pos, nrm, tris)]), mats, m, inflate_mode=1)
+    ds, osc, _ = _with_bvh(oracle_lib, sc, 96, 64)
+    try:
+        box = sc.bounding_box
+        o = rng.uniform(box[:3] - 0.2 * (box[3:] - box[:3]), box[3:] + 0.2 * (box[3:] - box[:3]), (20000, 3)).astype(np.float32)
+        d = rng.standard_normal((20000, 3))
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        for front in (True, False):
+            got = ds.intersect(o, d, 1e-3 * scale, front, use_bvh=True)
+            f, ids = osc.intersect_brute(o, d, 1e-3 * scale, front)
+            _check_hits(got, f, ids)
+            f, ids = osc.intersect(o, d, 1e-3 * scale, front, use_bvh=True)
+            _check_hits(got, f, ids)
+        assert (ids[:, 0] != NONE).mean() > (0.05 if scale >= 0.02 else -1)
+        w, h = 96, 64
+        p = ds.make_params(w, h, sc.camera.position, sc.pixel_to_ray_transform(w, h), spp=3, seed=9,
+                           flags=_lib.RT_FLAG_COUNT_WORK | _lib.RT_FLAG_ACCEL_BVH)
+        img, st = ds.render(p)
+        oimg, ost = osc.render_device_mode(osc.render_params(3, seed=9, flags=binding.FLAG_ACCEL_BVH), threads=16)
+        _assert_same_image_and_work(img, st, oimg, ost)
+    finally:
+        ds.close(); osc.close()
+
+
+def test_hierarchy_on_a_scene_received_as_bytes(oracle_lib):
+    """A process that got the scene as a byte buffer (one process per GPU) builds the hierarchy from those bytes."""
+    from raytracing_amd.render import serialize_scene
+    sc = scenes.cornell_scene(wall_grid=8, box_grid=3).preprocess()
+    rtd = RayTraceData(sc)
+    a, b = DeviceScene(rtd), DeviceScene.from_blob(serialize_scene(rtd))
+    try:
+        a.build_bvh(4); b.build_bvh(4)
+        p2r = sc.pixel_to_ray_transform(96, 64)
+        ia, _ = a.render(a.make_params(96, 64, sc.camera.position, p2r, spp=2, flags=_lib.RT_FLAG_ACCEL_BVH))
+        ib, _ = b.render(b.make_params(96, 64, sc.camera.position, p2r, spp=2, flags=_lib.RT_FLAG_ACCEL_BVH))
+        assert same_bits(ia, ib) and ia.max() > 0
+    finally:
+        a.close(); b.close()

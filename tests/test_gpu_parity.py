@@ -707,7 +707,8 @@ def test_cpp_host_layer_program_matches_python_path(tmp_path):
     assert (through != theirs).any(-1).mean() < 0.01
 
 
-def test_bench_two_rank_rehearsal_on_one_gpu():
+@pytest.mark.parametrize("accel", ["bsp", "bvh"])
+def test_bench_two_rank_rehearsal_on_one_gpu(accel):
     """bench.py's multi-rank path (bands per rank, gather, max-over-ranks timing, one JSON line from rank 0)
     with two ranks sharing this box's GPU and gloo as the transport (RT_BENCH_SHARE_GPU=1).  The rate it
     prints means nothing; the code path is what the 2/4/8-GPU runs use with RCCL."""
@@ -723,7 +724,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "2",
-           "--workload", "builtin"]
+           "--workload", "builtin", "--accel", accel]      # bvh: the rank that received the scene as bytes builds its own hierarchy
     run = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert run.returncode == 0, run.stderr[-3000:]
     lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
