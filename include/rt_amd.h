@@ -121,6 +121,12 @@ typedef struct {
  * inner leaf's box and inside no other leaf that holds the triangle: none in 469 000 rays of the built-in
  * scene, a few in 100 000 on large meshes.  The converged image is unchanged. */
 #define RT_FLAG_ACCEL_BVH 8u
+/* Per-lobe sampling, an estimator extension the reference does not have (it draws every continuation direction
+ * from the GGX lobe, src/render.hpp:145-167): the GGX half vector with probability pS, a cosine-weighted direction
+ * otherwise, pS = sum(f0) / (sum(f0) + pi * sum(adjustedColour)) held within [0.1, 0.9] (1 for a material without a
+ * diffuse part), weighted by BRDF * cos / (pS pdfS + (1 - pS) pdfD).  Same expectation, less variance on glossy
+ * dielectrics.  The lobe is chosen with the fourth word of the bounce's Philox block. */
+#define RT_FLAG_LOBE_SAMPLING 16u
 /* For the front_only argument of rt_intersect / rt_intersect_device: bit 0 = front faces only
  * (Surfaces::FRONT_ONLY, src/geometry.hpp:95-97), bit 1 = use the attached bounding volume hierarchy. */
 #define RT_INTERSECT_FRONT_ONLY 1

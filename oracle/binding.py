@@ -40,6 +40,7 @@ class RenderParams(ctypes.Structure):
 
 FLAG_RUSSIAN_ROULETTE = 4
 FLAG_ACCEL_BVH = 8
+FLAG_LOBE_SAMPLING = 16
 
 
 class Stats(ctypes.Structure):

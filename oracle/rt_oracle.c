@@ -1027,13 +1027,14 @@ void orc_sincos_2pi(float u, float* s, float* c) {
 }
 
 /* Two uniform numbers for dimension pair `dim` (0 = pixel jitter, b+1 = bounce b). */
-static inline void sampler_pair(sampler* sm, uint32_t dim, float* u0, float* u1raw, float* u2) {
-    if (!sm->deviceMode) { *u0 = rng_unit(sm->rng); *u1raw = rng_unit(sm->rng); *u2 = 0.0f; return; }
+static inline void sampler_pair(sampler* sm, uint32_t dim, float* u0, float* u1raw, float* u2, float* u3) {
+    if (!sm->deviceMode) { *u0 = rng_unit(sm->rng); *u1raw = rng_unit(sm->rng); *u2 = 0.0f; *u3 = 0.0f; return; }
     uint32_t ctr[4] = {sm->pixel, sm->sample, dim, 0u}, out[4];
     orc_philox4x32_10(ctr, sm->key, out);
     *u0 = orc_u32_to_unit_float(out[0]);
     *u1raw = orc_u32_to_unit_float(out[1]);
     *u2 = orc_u32_to_unit_float(out[2]);     /* third word of the same block: Russian roulette */
+    *u3 = orc_u32_to_unit_float(out[3]);     /* fourth word: choice of the lobe (per-lobe sampling) */
 }
 
 /* src/render.hpp:53-212.  The reference stores per-bounce terms in 8 AVX lanes and evaluates them
@@ -1042,6 +1043,7 @@ static inline void sampler_pair(sampler* sm, uint32_t dim, float* u0, float* u1r
  *   lightWeights[k] = w[k-1] * lightWeights[k-1], outgoing = fma(lightWeights[k], emission[k], outgoing). */
 static v3 ray_trace(const orc_scene* s, v3 o, v3 d, sampler* sm, uint32_t bounceLimit, float tMin, uint32_t flags, orc_stats* st) {
     int const roulette = (flags & ORC_FLAG_RUSSIAN_ROULETTE) != 0;
+    int const lobes = (flags & ORC_FLAG_LOBE_SAMPLING) != 0 && sm->deviceMode;
     int const mode = 1 | ((flags & ORC_FLAG_ACCEL_BVH) ? 2 : 0);
     v3 throughput = V(1.0f, 1.0f, 1.0f), light = V(0.0f, 0.0f, 0.0f);
     uint32_t bounce = 0;
@@ -1060,21 +1062,76 @@ static v3 ray_trace(const orc_scene* s, v3 o, v3 d, sampler* sm, uint32_t bounce
         if (nDotO < 0.0f) { nDotO = -nDotO; normal = neg3(normal); }
         v3 p1, p2;
         orthonormal_basis(normal, &p1, &p2);
-        float thetaParam, u1, u2;
-        sampler_pair(sm, bounce + 1, &thetaParam, &u1, &u2);
-        float cosThetaSq = 1.0f / (1.0f + m->ndfAlphaSq * thetaParam / (1.0f - thetaParam));
-        float cosTheta = sqrtf(cosThetaSq);
-        float sinTheta = sqrtf(1.0f - cosThetaSq);
+        float thetaParam, u1, u2, u3;
+        sampler_pair(sm, bounce + 1, &thetaParam, &u1, &u2, &u3);
         float sinPhi, cosPhi;
         if (sm->deviceMode) orc_sincos_2pi(u1, &sinPhi, &cosPhi);
         else { float phi = 6.28318530717958647692528676655900576f * u1; sinPhi = sinf(phi); cosPhi = cosf(phi); }
         v3 tangent = add3(scale3(p1, cosPhi), scale3(p2, sinPhi));
-        v3 halfway = add3(scale3(normal, cosTheta), scale3(tangent, sinTheta));
-        float hDotO = glm_dot(halfway, outgoing);
-        v3 incident = sub3(scale3(halfway, 2.0f * hDotO), outgoing);
-        float nDotI = glm_dot(normal, incident);
-        if (!(nDotI > 0.0f)) break;                                            /* :169-175 */
-        v3 w = bounce_weight(m, nDotO, nDotI, cosTheta, hDotO);
+        v3 incident, w;
+        if (!lobes) {
+            float cosThetaSq = 1.0f / (1.0f + m->ndfAlphaSq * thetaParam / (1.0f - thetaParam));
+            float cosTheta = sqrtf(cosThetaSq);
+            float sinTheta = sqrtf(1.0f - cosThetaSq);
+            v3 halfway = add3(scale3(normal, cosTheta), scale3(tangent, sinTheta));
+            float hDotO = glm_dot(halfway, outgoing);
+            incident = sub3(scale3(halfway, 2.0f * hDotO), outgoing);
+            float nDotI = glm_dot(normal, incident);
+            if (!(nDotI > 0.0f)) break;                                            /* :169-175 */
+            w = bounce_weight(m, nDotO, nDotI, cosTheta, hDotO);
+        }
+        else {
+            /* Per-lobe sampling (device mode only; not in the reference, which draws every direction from the GGX
+             * lobe, src/render.hpp:145-167): GGX half vector with probability pS, cosine-weighted direction otherwise,
+             * weight = BRDF * cos / (pS pdfS + (1 - pS) pdfD). */
+            float pi = 3.14159265358979323846264338327950288f;
+            float ws = m->f0.x + m->f0.y + m->f0.z;
+            float wd = (m->adjustedColour.x + m->adjustedColour.y + m->adjustedColour.z) * pi;
+            float pS = 1.0f;
+            if (wd > 0.0f) {
+                pS = ws / (ws + wd);
+                if (pS < 0.1f) pS = 0.1f;
+                if (pS > 0.9f) pS = 0.9f;
+            }
+            float nDotH, hDotO;
+            if (u3 < pS) {
+                float cosThetaSq = 1.0f / (1.0f + m->ndfAlphaSq * thetaParam / (1.0f - thetaParam));
+                nDotH = sqrtf(cosThetaSq);
+                float sinTheta = sqrtf(1.0f - cosThetaSq);
+                v3 halfway = add3(scale3(normal, nDotH), scale3(tangent, sinTheta));
+                hDotO = glm_dot(halfway, outgoing);
+                incident = sub3(scale3(halfway, 2.0f * hDotO), outgoing);
+            }
+            else {
+                float sinT = sqrtf(thetaParam), cosT = sqrtf(1.0f - thetaParam);
+                incident = add3(scale3(normal, cosT), scale3(tangent, sinT));
+                v3 halfway = glm_normalize(add3(outgoing, incident));
+                hDotO = glm_dot(halfway, outgoing);
+                nDotH = glm_dot(normal, halfway);
+            }
+            float nDotI = glm_dot(normal, incident);
+            if (!(nDotI > 0.0f && hDotO > 0.0f && nDotH > 0.0f)) break;
+            float omh = 1.0f - hDotO, tmp = 1.0f;
+            for (int i = 0; i < 5; ++i) tmp *= omh;
+            v3 F = V(fmaf(-m->f0.x, tmp, m->f0.x + tmp), fmaf(-m->f0.y, tmp, m->f0.y + tmp), fmaf(-m->f0.z, tmp, m->f0.z + tmp));
+            float nDotHSq = nDotH * nDotH;
+            float tanThetaSq = 1.0f / nDotHSq - 1.0f;
+            float aPlusTan = m->ndfAlphaSq + tanThetaSq;
+            float D = m->ndfAlphaSq / (pi * (nDotHSq * nDotHSq) * (aPlusTan * aPlusTan));
+            float ag = m->geometryAlphaSq;
+            float pI = 1.0f + sqrtf(1.0f + ag / (nDotI * nDotI) - ag);
+            float pO = 1.0f + sqrtf(1.0f + ag / (nDotO * nDotO) - ag);
+            float G = 4.0f / (pI * pO);
+            float pdfS = D * nDotH / (4.0f * hDotO);
+            float pdfD = nDotI / pi;
+            float pdf = pS * pdfS + (1.0f - pS) * pdfD;
+            if (!(pdf > 0.0f)) break;
+            float scale = nDotI / pdf;
+            float specular = nDotO > 0.0f ? D * G / (4.0f * nDotI * nDotO) : 0.0f;
+            v3 a = m->adjustedColour;
+            w = V((fmaf(-F.x, a.x, a.x) + F.x * specular) * scale, (fmaf(-F.y, a.y, a.y) + F.y * specular) * scale,
+                  (fmaf(-F.z, a.z, a.z) + F.z * specular) * scale);
+        }
         throughput = V(w.x * throughput.x, w.y * throughput.y, w.z * throughput.z);
         /* Russian roulette (device mode only; the reference has none, its paths end at the bounce limit,
          * src/render.hpp:117): from the third bounce on, survive with probability min(1, largest throughput
@@ -1127,8 +1184,8 @@ void orc_path_radiance_device_mode(const orc_scene* s, const orc_render_params* 
     sm.deviceMode = 1;
     sm.key[0] = (uint32_t)p->seed; sm.key[1] = (uint32_t)(p->seed >> 32);
     sm.pixel = pixelY * p->width + pixelX; sm.sample = sample;
-    float jx, jy, unused;
-    sampler_pair(&sm, 0, &jx, &jy, &unused);
+    float jx, jy, unused, unused2;
+    sampler_pair(&sm, 0, &jx, &jy, &unused, &unused2);
     float sx = (float)pixelX + jx, sy = (float)pixelY + jy;
     v3 d = camera_ray(p->pixelToRay, sx, sy);
     if (st) st->paths++;

@@ -124,6 +124,9 @@ typedef struct {
 #define ORC_FLAG_RUSSIAN_ROULETTE 4u
 /* Nearest-hit queries answered from the product's alternative accelerator (orc_scene_set_bvh4). */
 #define ORC_FLAG_ACCEL_BVH 8u
+/* Per-lobe sampling (an estimator extension of the product, not in the reference): GGX half vector or cosine-weighted
+ * direction, chosen with the fourth Philox word, weighted by the mixture density. */
+#define ORC_FLAG_LOBE_SAMPLING 16u
 
 typedef struct {
     uint64_t segments;               /* closest-hit queries issued by the path loop (src/render.hpp:104) */

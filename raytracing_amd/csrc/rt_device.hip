@@ -88,6 +88,7 @@ struct RenderConst {
     float tMin;
     uint32_t key0, key1;
     uint32_t roulette;          // RT_FLAG_RUSSIAN_ROULETTE
+    uint32_t lobes;             // RT_FLAG_LOBE_SAMPLING
     uint32_t rowGroup, rowSkip; // interleaved row groups: image row = y0 + r + (r / rowGroup) * rowSkip (rowSkip 0: plain rectangle)
 };
 
@@ -813,7 +814,7 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
 
 // Philox-4x32-10 keyed by the render seed; counter = (pixel index, sample index, dimension pair, 0).
 __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1, uint32_t& r0,
-                                       uint32_t& r1, uint32_t& r2) {
+                                       uint32_t& r1, uint32_t& r2, uint32_t& r3) {
     uint32_t c3 = 0;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -823,7 +824,7 @@ __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, ui
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    r0 = c0; r1 = c1; r2 = c2;
+    r0 = c0; r1 = c1; r2 = c2; r3 = c3;
 }
 __device__ __forceinline__ float unitFloat(uint32_t v) { return static_cast<float>(v >> 8) * 0x1p-24f; }
 
@@ -1003,8 +1004,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P,
         uint32_t lx, ly;
         slotPixel(p, R.w, R.h, lx, ly);
         uint32_t const px = R.x0 + lx, py = R.y0 + ly + (R.rowSkip ? (ly / R.rowGroup) * R.rowSkip : 0u);
-        uint32_t r0, r1, r2;
-        philox(py * R.width + px, sampleBase + sLocal, 0u, R.key0, R.key1, r0, r1, r2);
+        uint32_t r0, r1, r2, r3;
+        philox(py * R.width + px, sampleBase + sLocal, 0u, R.key0, R.key1, r0, r1, r2, r3);
         float const sx = static_cast<float>(px) + unitFloat(r0);
         float const sy = static_cast<float>(py) + unitFloat(r1);
         V3 const v = mk(R.m[0] * sx + R.m[3] * sy + R.m[6] * 1.0f, R.m[1] * sx + R.m[4] * sy + R.m[7] * 1.0f,
@@ -1135,42 +1136,103 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
                     uint32_t lx, ly;
                     slotPixel(p, R.w, R.h, lx, ly);
                     uint32_t const px = R.x0 + lx, py = R.y0 + ly + (R.rowSkip ? (ly / R.rowGroup) * R.rowSkip : 0u);
-                    uint32_t r0, r1, r2;
-                    philox(py * R.width + px, sampleBase + sLocal, bounce + 1u, R.key0, R.key1, r0, r1, r2);
+                    uint32_t r0, r1, r2, r3;
+                    philox(py * R.width + px, sampleBase + sLocal, bounce + 1u, R.key0, R.key1, r0, r1, r2, r3);
                     float const thetaParam = unitFloat(r0);
-                    float const cosThetaSq = 1.0f / (1.0f + ndfA * thetaParam / (1.0f - thetaParam));
-                    float const cosTheta = sqrtf(cosThetaSq);
-                    float const sinTheta = sqrtf(1.0f - cosThetaSq);
                     float sinPhi, cosPhi;
                     sincos2pi(unitFloat(r1), sinPhi, cosPhi);
                     V3 const tangent = p1 * cosPhi + p2 * sinPhi;
-                    V3 const halfway = normal * cosTheta + tangent * sinTheta;
-                    float const hDotO = dotU(halfway, outgoing);
-                    V3 const incident = halfway * (2.0f * hDotO) - outgoing;
-                    float const nDotI = dotU(normal, incident);
-                    if (nDotI > 0.0f) {                                          // src/render.hpp:169
-                        // Fresnel-Schlick, src/render.hpp:77-83
-                        float const omh = 1.0f - hDotO;
-                        float const pw = ((((1.0f * omh) * omh) * omh) * omh) * omh;
-                        V3 const F = mk(__fmaf_rn(-f0.x, pw, f0.x + pw), __fmaf_rn(-f0.y, pw, f0.y + pw),
-                                        __fmaf_rn(-f0.z, pw, f0.z + pw));
-                        // GGX distribution, src/render.hpp:58-63 (nDotH is the sampled cosTheta, :166)
-                        float const pi = 3.14159265358979323846264338327950288f;
-                        float const nDotHSq = cosTheta * cosTheta;
-                        float const tanSq = 1.0f / nDotHSq - 1.0f;
-                        float const aPlus = ndfA + tanSq;
-                        float const D = ndfA / (pi * (nDotHSq * nDotHSq) * (aPlus * aPlus));
-                        // Smith-GGX geometry, src/render.hpp:66-74
-                        float const gI = 1.0f + sqrtf(1.0f + geoA / (nDotI * nDotI) - geoA);
-                        float const gO = 1.0f + sqrtf(1.0f + geoA / (nDotO * nDotO) - geoA);
-                        float const G = 4.0f / (gI * gO);
-                        // src/render.hpp:191-193
-                        float const dScale = 4.0f * nDotI * hDotO / (D * cosTheta);
-                        float const sScale = G * hDotO / (nDotO * cosTheta);
-                        V3 const diffuse = mk(__fmaf_rn(-F.x, adj.x, adj.x) * dScale, __fmaf_rn(-F.y, adj.y, adj.y) * dScale,
-                                              __fmaf_rn(-F.z, adj.z, adj.z) * dScale);
-                        V3 const spec = nDotO > 0.0f ? mk(F.x * sScale, F.y * sScale, F.z * sScale) : mk(0.0f, 0.0f, 0.0f);
-                        V3 const w = diffuse + spec;
+                    float const pi = 3.14159265358979323846264338327950288f;
+                    V3 incident = mk(0.0f, 0.0f, 0.0f), w = incident;
+                    bool sampled = false;
+                    if (R.lobes == 0u) {
+                        // the reference's estimator: GGX sampling of the half vector, src/render.hpp:145-153
+                        float const cosThetaSq = 1.0f / (1.0f + ndfA * thetaParam / (1.0f - thetaParam));
+                        float const cosTheta = sqrtf(cosThetaSq);
+                        float const sinTheta = sqrtf(1.0f - cosThetaSq);
+                        V3 const halfway = normal * cosTheta + tangent * sinTheta;
+                        float const hDotO = dotU(halfway, outgoing);
+                        incident = halfway * (2.0f * hDotO) - outgoing;
+                        float const nDotI = dotU(normal, incident);
+                        if (nDotI > 0.0f) {                                          // src/render.hpp:169
+                            // Fresnel-Schlick, src/render.hpp:77-83
+                            float const omh = 1.0f - hDotO;
+                            float const pw = ((((1.0f * omh) * omh) * omh) * omh) * omh;
+                            V3 const F = mk(__fmaf_rn(-f0.x, pw, f0.x + pw), __fmaf_rn(-f0.y, pw, f0.y + pw),
+                                            __fmaf_rn(-f0.z, pw, f0.z + pw));
+                            // GGX distribution, src/render.hpp:58-63 (nDotH is the sampled cosTheta, :166)
+                            float const nDotHSq = cosTheta * cosTheta;
+                            float const tanSq = 1.0f / nDotHSq - 1.0f;
+                            float const aPlus = ndfA + tanSq;
+                            float const D = ndfA / (pi * (nDotHSq * nDotHSq) * (aPlus * aPlus));
+                            // Smith-GGX geometry, src/render.hpp:66-74
+                            float const gI = 1.0f + sqrtf(1.0f + geoA / (nDotI * nDotI) - geoA);
+                            float const gO = 1.0f + sqrtf(1.0f + geoA / (nDotO * nDotO) - geoA);
+                            float const G = 4.0f / (gI * gO);
+                            // src/render.hpp:191-193
+                            float const dScale = 4.0f * nDotI * hDotO / (D * cosTheta);
+                            float const sScale = G * hDotO / (nDotO * cosTheta);
+                            V3 const diffuse = mk(__fmaf_rn(-F.x, adj.x, adj.x) * dScale, __fmaf_rn(-F.y, adj.y, adj.y) * dScale,
+                                                  __fmaf_rn(-F.z, adj.z, adj.z) * dScale);
+                            V3 const spec = nDotO > 0.0f ? mk(F.x * sScale, F.y * sScale, F.z * sScale) : mk(0.0f, 0.0f, 0.0f);
+                            w = diffuse + spec;
+                            sampled = true;
+                        }
+                    }
+                    else {
+                        // Per-lobe sampling (RT_FLAG_LOBE_SAMPLING; the reference draws every direction from the GGX
+                        // lobe, src/render.hpp:145-167, however diffuse the material): with probability pS the GGX half
+                        // vector as above, otherwise a cosine-weighted direction; the weight is BRDF * cos / (pS pdfS +
+                        // (1 - pS) pdfD), the one-sample mixture estimator of the same integral.
+                        float const ws = f0.x + f0.y + f0.z;
+                        float const wd = (adj.x + adj.y + adj.z) * pi;
+                        float pS = 1.0f;
+                        if (wd > 0.0f) {
+                            pS = ws / (ws + wd);
+                            if (pS < 0.1f) pS = 0.1f;
+                            if (pS > 0.9f) pS = 0.9f;
+                        }
+                        float nDotH, hDotO;
+                        if (unitFloat(r3) < pS) {
+                            float const cosThetaSq = 1.0f / (1.0f + ndfA * thetaParam / (1.0f - thetaParam));
+                            nDotH = sqrtf(cosThetaSq);
+                            float const sinTheta = sqrtf(1.0f - cosThetaSq);
+                            V3 const halfway = normal * nDotH + tangent * sinTheta;
+                            hDotO = dotU(halfway, outgoing);
+                            incident = halfway * (2.0f * hDotO) - outgoing;
+                        }
+                        else {
+                            float const sinT = sqrtf(thetaParam), cosT = sqrtf(1.0f - thetaParam);
+                            incident = normal * cosT + tangent * sinT;
+                            V3 const halfway = normalizeU(outgoing + incident);
+                            hDotO = dotU(halfway, outgoing);
+                            nDotH = dotU(normal, halfway);
+                        }
+                        float const nDotI = dotU(normal, incident);
+                        if (nDotI > 0.0f && hDotO > 0.0f && nDotH > 0.0f) {
+                            float const omh = 1.0f - hDotO;
+                            float const pw = ((((1.0f * omh) * omh) * omh) * omh) * omh;
+                            V3 const F = mk(__fmaf_rn(-f0.x, pw, f0.x + pw), __fmaf_rn(-f0.y, pw, f0.y + pw),
+                                            __fmaf_rn(-f0.z, pw, f0.z + pw));
+                            float const nDotHSq = nDotH * nDotH;
+                            float const tanSq = 1.0f / nDotHSq - 1.0f;
+                            float const aPlus = ndfA + tanSq;
+                            float const D = ndfA / (pi * (nDotHSq * nDotHSq) * (aPlus * aPlus));
+                            float const gI = 1.0f + sqrtf(1.0f + geoA / (nDotI * nDotI) - geoA);
+                            float const gO = 1.0f + sqrtf(1.0f + geoA / (nDotO * nDotO) - geoA);
+                            float const G = 4.0f / (gI * gO);
+                            float const pdfS = D * nDotH / (4.0f * hDotO);
+                            float const pdfD = nDotI / pi;
+                            float const pdf = pS * pdfS + (1.0f - pS) * pdfD;
+                            float const scale = nDotI / pdf;
+                            float const specular = nDotO > 0.0f ? D * G / (4.0f * nDotI * nDotO) : 0.0f;
+                            w = mk((__fmaf_rn(-F.x, adj.x, adj.x) + F.x * specular) * scale,
+                                   (__fmaf_rn(-F.y, adj.y, adj.y) + F.y * specular) * scale,
+                                   (__fmaf_rn(-F.z, adj.z, adj.z) + F.z * specular) * scale);
+                            sampled = pdf > 0.0f;
+                        }
+                    }
+                    if (sampled) {
                         T = mk(w.x * T.x, w.y * T.y, w.z * T.z);                 // src/render.hpp:200-202
                         alive = true;
                         // Russian roulette (no counterpart in the reference, whose paths end only at the bounce
@@ -1284,8 +1346,8 @@ __global__ void k_selftest(int op, const float* __restrict__ a, const float* __r
     case 1: out[i] = sqrtf(a[i]); break;
     case 2: { float s, c; sincos2pi(a[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break; }
     case 3: {
-        uint32_t r0, r1, r2;
-        philox(__float_as_uint(a[i]), __float_as_uint(b[i]), 7u, 0x5EEDu, 0x1234u, r0, r1, r2);
+        uint32_t r0, r1, r2, r3;
+        philox(__float_as_uint(a[i]), __float_as_uint(b[i]), 7u, 0x5EEDu, 0x1234u, r0, r1, r2, r3);
         out[2 * i] = __uint_as_float(r0); out[2 * i + 1] = __uint_as_float(r1);
         break;
     }
@@ -1782,6 +1844,7 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
     R.bounceLimit = p->bounce_limit; R.tMin = p->t_min;
     R.key0 = static_cast<uint32_t>(p->seed); R.key1 = static_cast<uint32_t>(p->seed >> 32);
     R.roulette = (p->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u;
+    R.lobes = (p->flags & RT_FLAG_LOBE_SAMPLING) ? 1u : 0u;
     bool const interleaved = p->row_stride > 1u && p->row_group > 0u;
     R.rowGroup = interleaved ? p->row_group : 1u;
     R.rowSkip = interleaved ? p->row_group * (p->row_stride - 1u) : 0u;
