@@ -786,11 +786,14 @@ static inline float bvh_child_entry(v3 o, v3 r, const float* n, int k, float low
     float Ax = sx * r.x, Ay = sy * r.y, Az = sz * r.z;
     float Bx = (n[0] - o.x) * r.x, By = (n[1] - o.y) * r.y, Bz = (n[2] - o.z) * r.z;
     int sh = 8 * k;
-    float ax = fmaf((float)((w[4] >> sh) & 0xFFu), Ax, Bx), bx = fmaf((float)((w[7] >> sh) & 0xFFu), Ax, Bx);
-    float ay = fmaf((float)((w[5] >> sh) & 0xFFu), Ay, By), by = fmaf((float)((w[8] >> sh) & 0xFFu), Ay, By);
-    float az = fmaf((float)((w[6] >> sh) & 0xFFu), Az, Bz), bz = fmaf((float)((w[9] >> sh) & 0xFFu), Az, Bz);
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), lower));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), upper));
+    /* per axis the sign of r says which plane the line crosses first */
+    uint32_t nearX = r.x < 0.0f ? w[7] : w[4], farX = r.x < 0.0f ? w[4] : w[7];
+    uint32_t nearY = r.y < 0.0f ? w[8] : w[5], farY = r.y < 0.0f ? w[5] : w[8];
+    uint32_t nearZ = r.z < 0.0f ? w[9] : w[6], farZ = r.z < 0.0f ? w[6] : w[9];
+    float tn = fmaxf(fmaxf(fmaf((float)((nearX >> sh) & 0xFFu), Ax, Bx), fmaf((float)((nearY >> sh) & 0xFFu), Ay, By)),
+                     fmaxf(fmaf((float)((nearZ >> sh) & 0xFFu), Az, Bz), lower));
+    float tf = fminf(fminf(fmaf((float)((farX >> sh) & 0xFFu), Ax, Bx), fmaf((float)((farY >> sh) & 0xFFu), Ay, By)),
+                     fminf(fmaf((float)((farZ >> sh) & 0xFFu), Az, Bz), upper));
     return tn <= tf * (1.0f + 0x1p-22f) ? tn : INFINITY;
 }
 

@@ -47,6 +47,17 @@ def test_static_workspace_render_matches_allocating_render():
         out = torch.zeros(1920 * 1080 * 3, dtype=torch.float32, device="cuda")
         with pytest.raises(_lib.RtError, match="262144"):
             ds.render_device_static(big, out, stream=stream)
+        # the estimator extensions and the alternative accelerator run on the same fixed workspace
+        ds.build_bvh(4)
+        flags = _lib.RT_FLAG_ACCEL_BVH | _lib.RT_FLAG_LOBE_SAMPLING | _lib.RT_FLAG_RUSSIAN_ROULETTE | _lib.RT_FLAG_COUNT_WORK
+        p = ds.make_params(w, h, sc.camera.position, p2r, spp=3, seed=5, rect=(10, 20, 200, 100), flags=flags)
+        a = torch.zeros(200 * 100 * 3, dtype=torch.float32, device="cuda")
+        b = torch.zeros_like(a)
+        st_a = ds.render_device(p, a, stream=stream)
+        st_b = ds.render_device_static(p, b, stream=stream)
+        torch.cuda.synchronize()
+        assert same_bits(a.cpu().numpy(), b.cpu().numpy()) and float(a.max()) > 0
+        assert st_a["segments"] == st_b["segments"] and st_a["inode_visits"] == st_b["inode_visits"]
         prof = ds.make_params(w, h, sc.camera.position, p2r, spp=1, rect=(0, 0, 64, 64), flags=_lib.RT_FLAG_PROFILE_KERNELS)
         with pytest.raises(_lib.RtError, match="PROFILE"):
             ds.render_device_static(prof, out, stream=stream)
