@@ -678,17 +678,29 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
                 int const k2 = (t0 <= t2) + (t1 <= t2) + (t3 < t2);
                 int const k3 = (t0 <= t3) + (t1 <= t3) + (t2 <= t3);
                 // the nearest becomes current, the other hit children go on the stack, farthest lowest
-#define RT_BVH_DEFER(k, child)                                                                            \
-                if ((k) >= 1 && (k) < nHit) {                                                              \
-                    int const pos = sp + nHit - 1 - (k);                                                   \
-                    if (!SPILL || pos < RT_BVH_LDS_STACK) stack[pos * RT_BLOCK] = (child);               \
-                    else spillStack[pos - RT_BVH_LDS_STACK] = (child);                                   \
+                // Unconditional stores when the LDS part of the stack has room: a child that is not deferred (the
+                // nearest, or one the line misses) is written to the first free slot above the new top, where it
+                // harms nothing.
+                int const top = sp + nHit - 1;
+                if (!SPILL || top < RT_BVH_LDS_STACK) {
+                    stack[((k0 >= 1 && k0 < nHit) ? top - k0 : top) * RT_BLOCK] = c0;
+                    stack[((k1 >= 1 && k1 < nHit) ? top - k1 : top) * RT_BLOCK] = c1;
+                    stack[((k2 >= 1 && k2 < nHit) ? top - k2 : top) * RT_BLOCK] = c2;
+                    stack[((k3 >= 1 && k3 < nHit) ? top - k3 : top) * RT_BLOCK] = c3;
                 }
-                RT_BVH_DEFER(k0, c0)
-                RT_BVH_DEFER(k1, c1)
-                RT_BVH_DEFER(k2, c2)
-                RT_BVH_DEFER(k3, c3)
+                else {
+#define RT_BVH_DEFER(k, child)                                                                            \
+                    if ((k) >= 1 && (k) < nHit) {                                                          \
+                        int const pos = top - (k);                                                         \
+                        if (pos < RT_BVH_LDS_STACK) stack[pos * RT_BLOCK] = (child);                       \
+                        else spillStack[pos - RT_BVH_LDS_STACK] = (child);                                 \
+                    }
+                    RT_BVH_DEFER(k0, c0)
+                    RT_BVH_DEFER(k1, c1)
+                    RT_BVH_DEFER(k2, c2)
+                    RT_BVH_DEFER(k3, c3)
 #undef RT_BVH_DEFER
+                }
                 cur = k0 == 0 ? c0 : (k1 == 0 ? c1 : (k2 == 0 ? c2 : c3));
                 sp += nHit - 1;
             }
@@ -762,17 +774,29 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             int const k2 = (t0 <= t2) + (t1 <= t2) + (t3 < t2);
             int const k3 = (t0 <= t3) + (t1 <= t3) + (t2 <= t3);
             // the nearest becomes current, the other hit children go on the stack, farthest lowest
-#define RT_BVH_DEFER(k, child)                                                                            \
-            if ((k) >= 1 && (k) < nHit) {                                                                  \
-                int const pos = sp + nHit - 1 - (k);                                                       \
-                if (!SPILL || pos < RT_BVH_LDS_STACK) stack[pos * RT_BLOCK] = (child);                   \
-                else spillStack[pos - RT_BVH_LDS_STACK] = (child);                                       \
+            // Unconditional stores when the LDS part of the stack has room: a child that is not deferred (the
+            // nearest, or one the line misses) is written to the first free slot above the new top, where it
+            // harms nothing.
+            int const top = sp + nHit - 1;
+            if (!SPILL || top < RT_BVH_LDS_STACK) {
+                stack[((k0 >= 1 && k0 < nHit) ? top - k0 : top) * RT_BLOCK] = c0;
+                stack[((k1 >= 1 && k1 < nHit) ? top - k1 : top) * RT_BLOCK] = c1;
+                stack[((k2 >= 1 && k2 < nHit) ? top - k2 : top) * RT_BLOCK] = c2;
+                stack[((k3 >= 1 && k3 < nHit) ? top - k3 : top) * RT_BLOCK] = c3;
             }
-            RT_BVH_DEFER(k0, c0)
-            RT_BVH_DEFER(k1, c1)
-            RT_BVH_DEFER(k2, c2)
-            RT_BVH_DEFER(k3, c3)
+            else {
+#define RT_BVH_DEFER(k, child)                                                                            \
+                if ((k) >= 1 && (k) < nHit) {                                                          \
+                    int const pos = top - (k);                                                         \
+                    if (pos < RT_BVH_LDS_STACK) stack[pos * RT_BLOCK] = (child);                       \
+                    else spillStack[pos - RT_BVH_LDS_STACK] = (child);                                 \
+                }
+                RT_BVH_DEFER(k0, c0)
+                RT_BVH_DEFER(k1, c1)
+                RT_BVH_DEFER(k2, c2)
+                RT_BVH_DEFER(k3, c3)
 #undef RT_BVH_DEFER
+            }
             cur = k0 == 0 ? c0 : (k1 == 0 ? c1 : (k2 == 0 ? c2 : c3));
             sp += nHit - 1;
         }
@@ -1893,7 +1917,7 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
     uint32_t slotGroup = 1u;
     if (const char* text = std::getenv("RT_AMD_SLOT_GROUP")) slotGroup = static_cast<uint32_t>(std::max(1, std::atoi(text)));
     bool const bvh = (p->flags & RT_FLAG_ACCEL_BVH) != 0;
-    bool const spill = bvh ? s->bvhStackNeed > RT_BVH_LDS_STACK : s->depth > RT_LDS_STACK_DEPTH;
+    bool const spill = bvh ? s->bvhStackNeed >= RT_BVH_LDS_STACK : s->depth > RT_LDS_STACK_DEPTH;    // the hierarchy's kernels keep one slot free above the top
     int const traceCap = (bvh ? s->gridTraceBvh : s->gridTrace)[countWork ? 1 : 0][spill ? 1 : 0];
     DevScene const& dev = bvh ? s->devBvh : s->dev;
     for (uint32_t done = 0; done < p->spp; done += spb) {
@@ -2058,7 +2082,7 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
     bool const bvh = (front_only & RT_INTERSECT_BVH) != 0;
     bool const front = (front_only & ~RT_INTERSECT_BVH) != 0;
     if (bvh && !s->hasBvh) return fail(RT_ERR_INVALID, "rt_intersect: RT_INTERSECT_BVH without a hierarchy attached (rt_scene_attach_bvh4)");
-    bool const spill = bvh ? s->bvhStackNeed > RT_BVH_LDS_STACK : s->depth > RT_LDS_STACK_DEPTH;
+    bool const spill = bvh ? s->bvhStackNeed >= RT_BVH_LDS_STACK : s->depth > RT_LDS_STACK_DEPTH;    // the hierarchy's kernels keep one slot free above the top
     int const cap = (bvh ? s->gridIntersectBvh : s->gridIntersect)[front ? 1 : 0][spill ? 1 : 0];
     DevScene const& dev = bvh ? s->devBvh : s->dev;
     for (uint64_t done = 0; done < n; done += slice) {
