@@ -25,7 +25,7 @@ int rt_internal_fail(int code, const char* message);
 
 namespace {
 
-constexpr int kBins = 16;
+constexpr int kBins = 64;
 constexpr uint32_t kMaxDepth2 = 48;         // binary levels before splits fall back to medians
 constexpr uint32_t kParallelGrain = 1u << 15;
 
