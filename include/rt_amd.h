@@ -145,7 +145,7 @@ typedef struct {
     float pixel_to_ray[9];        /* column-major mat3 {right, down, o}, src/camera.hpp:45 */
     uint32_t flags;
     uint32_t max_batch_paths;     /* paths traced together; 0 = as many as the call has, within 2^30 paths and half
-                                   * of the GPU's memory (76 bytes of workspace per path) */
+                                   * of the GPU's memory (80 bytes of workspace per path) */
     /* Interleaved row groups, for sharding one frame over several GPUs with a single call per GPU: with
      * row_stride > 1, row r of the output (0 <= r < h) is image row y0 + (r / row_group) * row_group * row_stride
      * + r % row_group, i.e. this call renders every row_stride-th group of row_group rows, starting at y0.
@@ -207,7 +207,7 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_o
 
 /* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and same image, bit
- * for bit, but the path state lives in a fixed array inside the library's code object (about 21 MiB per
+ * for bit, but the path state lives in a fixed array inside the library's code object (about 22 MiB per
  * GPU, held until the process ends) instead of buffers grown with hipMalloc, and the call allocates
  * nothing.  Limits: the rectangle holds at most RT_STATIC_MAX_PIXELS pixels (RT_ERR_LIMIT beyond that);
  * each batch traces at most that many paths, so large sample counts take more, smaller batches;

@@ -62,13 +62,14 @@ int fail(int code, const std::string& msg) {
 // What only shading needs sits in a parallel array, leafIds: {mesh, tri, gtri, 0} with gtri the
 // scene-wide index of the instantiated triangle; keeping it out of the records makes the traversal's
 // working set a quarter smaller.
-// Triangle normals, 48 bytes per gtri: the three instantiated vertex normals, padded to 3 float4.
+// Shading records, 48 bytes per triangle record (same index): {model, vn1.xyz} {vn2.xyz, vn3.x} {vn3.yz, 0, 0} -- the model
+// (for the material) and the three instantiated vertex normals, so that shading needs one dependent fetch per hit.
 // Material, 48 bytes per model: {ndfAlphaSq geomAlphaSq f0.x f0.y} {f0.z adj.x adj.y adj.z} {em.x em.y em.z 0}.
 struct DevScene {
     const float4* nodes;
     const float4* leafTris;
     const uint4* leafIds;
-    const float4* triNormals;
+    const float4* shadeRecs;        // per triangle record (same index as leafTris): what shading needs, see below
     const float4* materials;
     float boxAbsMax;       // largest |coordinate| of the root box: see filterMargin
     float rootLo[3], rootHi[3];     // the root box (BSPTree::_root.box), used by the hierarchy traversal
@@ -973,11 +974,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect_bvh(DevScene S, const fl
 
 // Path state, structure of arrays over the batch's path slots (slot = sampleInBatch * pixels + pixel):
 //   A = {origin.xyz, dir.x}   B = {dir.y, dir.z, throughput.x, throughput.y}
-//   C = {throughput.z, radiance.xyz}
+//   Tz = throughput.z   L = {radiance.xyz, 0}, touched only when a path meets an emitter (and by k_accumulate)
 struct PathState {
     float4* A;
     float4* B;
-    float4* C;
+    float* Tz;
+    float4* L;
     float4* hit;          // {t, u, v, ref}
     uint32_t* queue[2];   // path slots still alive, ping-pong
     uint32_t* counts;     // counts[b] = number of paths entering bounce b
@@ -1054,7 +1056,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P,
         V3 const d = normalizeU(v);
         P.A[id] = make_float4(R.camPos[0], R.camPos[1], R.camPos[2], d.x);
         P.B[id] = make_float4(d.y, d.z, 1.0f, 1.0f);
-        P.C[id] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        P.Tz[id] = 1.0f;
+        P.L[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) P.counts[0] = paths;
 }
@@ -1140,22 +1143,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
             uint32_t const ref = __float_as_uint(H.w);
             if (ref != 0xFFFFFFFFu) {
                 float4 const A = P.A[slot], B = P.B[slot];
-                float4 C = P.C[slot];
+                float const Tz = P.Tz[slot];
                 V3 const o = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
-                V3 T = mk(B.z, B.w, C.x), L = mk(C.y, C.z, C.w);
-                uint4 const ids = S.leafIds[ref];
-                uint32_t const mesh = ids.x, gtri = ids.z;
+                V3 T = mk(B.z, B.w, Tz);
+                float4 const n0 = S.shadeRecs[3 * static_cast<size_t>(ref)];
+                uint32_t const mesh = __float_as_uint(n0.x);
                 float4 const m0 = S.materials[3 * mesh], m1 = S.materials[3 * mesh + 1], m2 = S.materials[3 * mesh + 2];
                 float const ndfA = m0.x, geoA = m0.y;
                 V3 const f0 = mk(m0.z, m0.w, m1.x), adj = mk(m1.y, m1.z, m1.w), em = mk(m2.x, m2.y, m2.z);
-                // outgoingLight = fma(lightWeight, emission, outgoingLight), src/render.hpp:206
-                L = mk(__fmaf_rn(T.x, em.x, L.x), __fmaf_rn(T.y, em.y, L.y), __fmaf_rn(T.z, em.z, L.z));
+                // outgoingLight = fma(lightWeight, emission, outgoingLight), src/render.hpp:206.  With a zero emission and
+                // a finite throughput the sum is the radiance itself, bit for bit, so the radiance is read and written
+                // only at emitters (and where the throughput is no longer finite: 0 * inf must still turn it into NaN).
+                bool const finiteT = fabsf(T.x) < INFINITY && fabsf(T.y) < INFINITY && fabsf(T.z) < INFINITY;
+                if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f || !finiteT) {
+                    float4 const Lr = P.L[slot];
+                    P.L[slot] = make_float4(__fmaf_rn(T.x, em.x, Lr.x), __fmaf_rn(T.y, em.y, Lr.y), __fmaf_rn(T.z, em.z, Lr.z), 0.0f);
+                }
                 if (bounce < R.bounceLimit) {                                    // src/render.hpp:117
                     ++shaded;
-                    float4 const n0 = S.triNormals[3 * static_cast<size_t>(gtri)],
-                                 n1 = S.triNormals[3 * static_cast<size_t>(gtri) + 1],
-                                 n2 = S.triNormals[3 * static_cast<size_t>(gtri) + 2];
-                    V3 const vn1 = mk(n0.x, n0.y, n0.z), vn2 = mk(n0.w, n1.x, n1.y), vn3 = mk(n1.z, n1.w, n2.x);
+                    float4 const n1 = S.shadeRecs[3 * static_cast<size_t>(ref) + 1], n2 = S.shadeRecs[3 * static_cast<size_t>(ref) + 2];
+                    V3 const vn1 = mk(n0.y, n0.z, n0.w), vn2 = mk(n1.x, n1.y, n1.z), vn3 = mk(n1.w, n2.x, n2.y);
                     float const c2 = H.y, c3 = H.z;
                     float const c1 = 1.0f - c2 - c3;
                     V3 normal = vn1 * c1 + vn2 * c2 + vn3 * c3;                  // src/render.hpp:128-129
@@ -1292,11 +1299,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
                             V3 const point = mk(o.x + H.x * d.x, o.y + H.x * d.y, o.z + H.x * d.z);
                             P.A[slot] = make_float4(point.x, point.y, point.z, incident.x);
                             P.B[slot] = make_float4(incident.y, incident.z, T.x, T.y);
+                            P.Tz[slot] = T.z;
                         }
                     }
                 }
-                C = make_float4(T.z, L.x, L.y, L.z);
-                P.C[slot] = C;
             }
         }
         // Stream compaction: ballot, prefix count below the lane.  Survivors are staged in LDS per wave
@@ -1344,16 +1350,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathState P, float* __r
         // four fetches in flight; the additions stay in sample order
         uint32_t s = 0;
         for (; s + 4u <= M.samples; s += 4u) {
-            float4 const C0 = P.C[first + s * stride], C1 = P.C[first + (s + 1u) * stride],
-                         C2 = P.C[first + (s + 2u) * stride], C3 = P.C[first + (s + 3u) * stride];
-            r = r + C0.y; g = g + C0.z; b = b + C0.w;
-            r = r + C1.y; g = g + C1.z; b = b + C1.w;
-            r = r + C2.y; g = g + C2.z; b = b + C2.w;
-            r = r + C3.y; g = g + C3.z; b = b + C3.w;
+            float4 const C0 = P.L[first + s * stride], C1 = P.L[first + (s + 1u) * stride],
+                         C2 = P.L[first + (s + 2u) * stride], C3 = P.L[first + (s + 3u) * stride];
+            r = r + C0.x; g = g + C0.y; b = b + C0.z;
+            r = r + C1.x; g = g + C1.y; b = b + C1.z;
+            r = r + C2.x; g = g + C2.y; b = b + C2.z;
+            r = r + C3.x; g = g + C3.y; b = b + C3.z;
         }
         for (; s < M.samples; ++s) {
-            float4 const C = P.C[first + s * stride];
-            r = r + C.y; g = g + C.z; b = b + C.w;
+            float4 const C = P.L[first + s * stride];
+            r = r + C.x; g = g + C.y; b = b + C.z;
         }
         if (last) {
             uint32_t x, y;
@@ -1408,7 +1414,8 @@ __global__ void k_selftest(int op, const float* __restrict__ a, const float* __r
 // grown on demand (rt_render_device), and a fixed-size one carved out of the file-scope `scratch`
 // array (rt_render_device_static), which never allocates.
 struct Workspace {
-    float4 *A = nullptr, *B = nullptr, *C = nullptr, *hit = nullptr;
+    float4 *A = nullptr, *B = nullptr, *L = nullptr, *hit = nullptr;
+    float* Tz = nullptr;
     uint32_t *q0 = nullptr, *q1 = nullptr;
     uint32_t* counts = nullptr;         // 1024 words: per-bounce queue sizes, then the trace kernels' fetch cursors
     Counters* counters = nullptr;
@@ -1440,6 +1447,7 @@ struct rt_scene {
     void* dBvhNodes = nullptr;
     void* dBvhTris = nullptr;
     void* dBvhIds = nullptr;
+    void* dBvhShade = nullptr;
     uint32_t bvhStackNeed = 0, bvhNodeCount = 0;
     bool bvhMerged = false;              // which traversal shape the hierarchy's size calls for (see attachBvh)
     int gridTraceBvh[2][2] = {{0, 0}, {0, 0}};          // [count][spill], for the shape chosen
@@ -1455,11 +1463,11 @@ struct rt_scene {
 // ---- allocation-free workspace -------------------------------------------------------------------
 // rt_render_device_static keeps its whole path state in this array: no hipMalloc, hipFree or any other
 // allocating call on its path.  Layout (bytes): queue sizes and fetch cursors 4096 | counters 4096 |
-// A, B, C, hit 16*P each | two queues 4*P each | accumulator 12*P, with P = RT_STATIC_MAX_PATHS path
+// A, B, L, hit 16*P each | two queues 4*P each | accumulator 12*P | throughput.z 4*P, with P = RT_STATIC_MAX_PATHS path
 // slots (and at most P pixels per call).  Every GPU holds its own copy at its own address; the host-side
 // name is only a handle for hipGetSymbolAddress, never a device address.
 #define RT_STATIC_MAX_PATHS (1u << 18)
-#define RT_STATIC_BYTES (8192ull + 84ull * RT_STATIC_MAX_PATHS)
+#define RT_STATIC_BYTES (8192ull + 88ull * RT_STATIC_MAX_PATHS)
 #define RT_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_BYTES];
 
@@ -1486,11 +1494,12 @@ int bindStaticWorkspace(rt_scene* s) {
     unsigned char* q = base + 8192;
     W.A = reinterpret_cast<float4*>(q); q += 16 * P;
     W.B = reinterpret_cast<float4*>(q); q += 16 * P;
-    W.C = reinterpret_cast<float4*>(q); q += 16 * P;
+    W.L = reinterpret_cast<float4*>(q); q += 16 * P;
     W.hit = reinterpret_cast<float4*>(q); q += 16 * P;
     W.q0 = reinterpret_cast<uint32_t*>(q); q += 4 * P;
     W.q1 = reinterpret_cast<uint32_t*>(q); q += 4 * P;
-    W.accum = reinterpret_cast<float*>(q);
+    W.accum = reinterpret_cast<float*>(q); q += 12 * P;
+    W.Tz = reinterpret_cast<float*>(q);
     W.paths = P;
     W.pixels = P;
     return RT_OK;
@@ -1498,10 +1507,11 @@ int bindStaticWorkspace(rt_scene* s) {
 
 void freeWorkspace(rt_scene* s) {
     Workspace& W = s->ws;
-    for (void* p : {static_cast<void*>(W.A), static_cast<void*>(W.B), static_cast<void*>(W.C), static_cast<void*>(W.hit),
+    for (void* p : {static_cast<void*>(W.A), static_cast<void*>(W.B), static_cast<void*>(W.L), static_cast<void*>(W.hit), static_cast<void*>(W.Tz),
                     static_cast<void*>(W.q0), static_cast<void*>(W.q1), static_cast<void*>(W.accum)})
         if (p) (void)hipFree(p);
-    W.A = W.B = W.C = W.hit = nullptr;
+    W.A = W.B = W.L = W.hit = nullptr;
+    W.Tz = nullptr;
     W.q0 = W.q1 = nullptr;
     W.accum = nullptr;
     W.paths = 0;
@@ -1563,6 +1573,37 @@ int guarded(const char* what, Body&& body) {
 int rt_internal_fail(int code, const char* message) { return fail(code, message ? message : ""); }
 
 namespace {
+
+// The three instantiated vertex normals of every triangle of the scene (9 floats per scene-wide triangle index),
+// RayTraceData::vertexNormals looked up through tris / triRanges / vertexRanges as src/render.hpp:121-129 does.
+int gatherTriNormals(const rt_scene_desc* D, const char* who, std::vector<float>& out) {
+    out.assign(9 * static_cast<size_t>(std::max<uint32_t>(D->pretri_count, 1)), 0.0f);
+    for (uint32_t m = 0; m < D->model_count; ++m) {
+        uint32_t const tb = D->model_pretri_begin[m], te = D->model_pretri_begin[m + 1];
+        uint32_t const vb = D->model_vertex_begin[m], ve = D->model_vertex_begin[m + 1];
+        if (te < tb || ve < vb || te > D->pretri_count || ve > D->vertex_count)
+            return fail(RT_ERR_INVALID, std::string(who) + ": offsets not ascending");
+        if (static_cast<uint64_t>(D->model_tri_begin[m]) + (te - tb) > D->base_tri_count)
+            return fail(RT_ERR_INVALID, std::string(who) + ": model triangle range outside base_tris");
+        for (uint32_t k = 0; k < te - tb; ++k) {
+            uint32_t const* idx = D->base_tris + 3 * (static_cast<size_t>(D->model_tri_begin[m]) + k);
+            float* o = out.data() + 9 * static_cast<size_t>(tb + k);
+            for (int j = 0; j < 3; ++j) {
+                if (idx[j] >= ve - vb) return fail(RT_ERR_INVALID, std::string(who) + ": vertex index outside model");
+                std::memcpy(o + 3 * j, D->vertex_normals + 3 * static_cast<size_t>(vb + idx[j]), 12);
+            }
+        }
+    }
+    return RT_OK;
+}
+
+// One 48-byte shading record: {model, vn1.xyz} {vn2.xyz, vn3.x} {vn3.yz, 0, 0}.
+void shadeRecord(float* rec, uint32_t model, const float* normals9) {
+    std::memcpy(rec, &model, 4);
+    std::memcpy(rec + 1, normals9, 36);
+    rec[10] = 0.0f;
+    rec[11] = 0.0f;
+}
 
 int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     if (!D || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
@@ -1661,22 +1702,16 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
         uint32_t const ids[4] = {ref.mesh, ref.tri, gtri, 0u};
         std::memcpy(leafIds.data() + 4 * static_cast<size_t>(r), ids, 16);
     }
-    std::vector<float> triNormals(12 * static_cast<size_t>(std::max<uint32_t>(D->pretri_count, 1)), 0.0f);
-    for (uint32_t m = 0; m < D->model_count; ++m) {
-        uint32_t const tb = D->model_pretri_begin[m], te = D->model_pretri_begin[m + 1];
-        uint32_t const vb = D->model_vertex_begin[m], ve = D->model_vertex_begin[m + 1];
-        if (te < tb || ve < vb) return fail(RT_ERR_INVALID, "rt_scene_create: offsets not ascending");
-        if (static_cast<uint64_t>(D->model_tri_begin[m]) + (te - tb) > D->base_tri_count)
-            return fail(RT_ERR_INVALID, "rt_scene_create: model triangle range outside base_tris");
-        for (uint32_t k = 0; k < te - tb; ++k) {
-            uint32_t const* idx = D->base_tris + 3 * (static_cast<size_t>(D->model_tri_begin[m]) + k);
-            float* o = triNormals.data() + 12 * static_cast<size_t>(tb + k);
-            for (int j = 0; j < 3; ++j) {
-                if (idx[j] >= ve - vb) return fail(RT_ERR_INVALID, "rt_scene_create: vertex index outside model");
-                std::memcpy(o + 3 * j, D->vertex_normals + 3 * static_cast<size_t>(vb + idx[j]), 12);
-            }
-        }
+    std::vector<float> triNormals;
+    {
+        int const rc = gatherTriNormals(D, "rt_scene_create", triNormals);
+        if (rc != RT_OK) return rc;
     }
+    // shading records in the order of the leaf triangle records
+    std::vector<float> shadeRecs(12 * static_cast<size_t>(std::max<uint32_t>(refCount, 1)), 0.0f);
+    for (uint32_t r = 0; r < refCount; ++r)
+        shadeRecord(shadeRecs.data() + 12 * static_cast<size_t>(r), leafIds[4 * static_cast<size_t>(r)],
+                    triNormals.data() + 9 * static_cast<size_t>(leafIds[4 * static_cast<size_t>(r) + 2]));
 
     // ---- upload ---------------------------------------------------------------------------------
     int count = 0;
@@ -1704,7 +1739,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     hipError_t e = upload(&s->dNodes, nodes.data(), nodes.size() * sizeof(HNode));
     if (e == hipSuccess) e = upload(&s->dLeafTris, leafTris.data(), leafTris.size() * 4);
     if (e == hipSuccess) e = upload(&s->dLeafIds, leafIds.data(), leafIds.size() * 4);
-    if (e == hipSuccess) e = upload(&s->dTriNormals, triNormals.data(), triNormals.size() * 4);
+    if (e == hipSuccess) e = upload(&s->dTriNormals, shadeRecs.data(), shadeRecs.size() * 4);
     if (e == hipSuccess) e = upload(&s->dMaterials, mats.data(), matBytes);
     if (e == hipSuccess) e = hipMalloc(&dCounts, 4096);
     s->ws.counts = static_cast<uint32_t*>(dCounts);
@@ -1714,7 +1749,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     s->dev.nodes = static_cast<const float4*>(s->dNodes);
     s->dev.leafTris = static_cast<const float4*>(s->dLeafTris);
     s->dev.leafIds = static_cast<const uint4*>(s->dLeafIds);
-    s->dev.triNormals = static_cast<const float4*>(s->dTriNormals);
+    s->dev.shadeRecs = static_cast<const float4*>(s->dTriNormals);
     s->dev.materials = static_cast<const float4*>(s->dMaterials);
     s->dev.boxAbsMax = 0.0f;
     for (int k = 0; k < 3; ++k) { s->dev.rootLo[k] = nodes[0].lo[k]; s->dev.rootHi[k] = nodes[0].hi[k]; }
@@ -1740,9 +1775,9 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
 }
 
 void freeBvh(rt_scene* s) {
-    for (void* p : {s->dBvhNodes, s->dBvhTris, s->dBvhIds})
+    for (void* p : {s->dBvhNodes, s->dBvhTris, s->dBvhIds, s->dBvhShade})
         if (p) (void)hipFree(p);
-    s->dBvhNodes = s->dBvhTris = s->dBvhIds = nullptr;
+    s->dBvhNodes = s->dBvhTris = s->dBvhIds = s->dBvhShade = nullptr;
     s->hasBvh = false;
 }
 
@@ -1791,7 +1826,14 @@ int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, ui
     // ---- triangle records and ids in the hierarchy's order -----------------------------------------------
     std::vector<float> tris(12 * static_cast<size_t>(std::max<uint32_t>(triCount, 1)), 0.0f);
     std::vector<uint32_t> ids(4 * static_cast<size_t>(std::max<uint32_t>(triCount, 1)), 0u);
+    std::vector<float> shadeRecs(12 * static_cast<size_t>(std::max<uint32_t>(triCount, 1)), 0.0f);
     {
+        if (D->model_count && (!D->model_vertex_begin || !D->model_tri_begin || (D->vertex_count && !D->vertex_normals)
+                               || (D->base_tri_count && !D->base_tris)))
+            return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: null array in description");
+        std::vector<float> triNormals;
+        int const rcn = gatherTriNormals(D, "rt_scene_attach_bvh4", triNormals);
+        if (rcn != RT_OK) return rcn;
         std::vector<uint8_t> used(std::max<uint32_t>(triCount, 1), 0);
         uint32_t model = 0;
         std::vector<uint32_t> modelOf(std::max<uint32_t>(triCount, 1), 0u);
@@ -1807,6 +1849,7 @@ int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, ui
             uint32_t const m = modelOf[g];
             uint32_t const rec[4] = {m, g - D->model_pretri_begin[m], g, 0u};
             std::memcpy(ids.data() + 4 * static_cast<size_t>(k), rec, 16);
+            shadeRecord(shadeRecs.data() + 12 * static_cast<size_t>(k), m, triNormals.data() + 9 * static_cast<size_t>(g));
         }
     }
     // ---- upload ---------------------------------------------------------------------------------------------
@@ -1822,6 +1865,7 @@ int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, ui
     hipError_t e = upload(&s->dBvhNodes, nodes, sizeof(rt_bvh4_node) * static_cast<size_t>(nodeCount));
     if (e == hipSuccess) e = upload(&s->dBvhTris, tris.data(), tris.size() * 4);
     if (e == hipSuccess) e = upload(&s->dBvhIds, ids.data(), ids.size() * 4);
+    if (e == hipSuccess) e = upload(&s->dBvhShade, shadeRecs.data(), shadeRecs.size() * 4);
     if (e != hipSuccess) {
         freeBvh(s);
         return fail(RT_ERR_HIP, std::string("rt_scene_attach_bvh4: upload failed: ") + hipGetErrorString(e));
@@ -1830,6 +1874,7 @@ int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, ui
     s->devBvh.nodes = static_cast<const float4*>(s->dBvhNodes);
     s->devBvh.leafTris = static_cast<const float4*>(s->dBvhTris);
     s->devBvh.leafIds = static_cast<const uint4*>(s->dBvhIds);
+    s->devBvh.shadeRecs = static_cast<const float4*>(s->dBvhShade);
     s->devBvh.refillMin = 16u;        // measured flat between 8 and 24 (3 % better than storing and fetching lane by lane)
     if (const char* text = std::getenv("RT_AMD_BVH_REFILL")) s->devBvh.refillMin = static_cast<uint32_t>(std::max(1, std::atoi(text)));     // tuning aid
     s->bvhStackNeed = need[0];
@@ -1875,7 +1920,7 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
     uint32_t const bounceCount = p->bounce_limit + 1;      // intersections per path, src/render.hpp:88
 
     PathState P;
-    P.A = W.A; P.B = W.B; P.C = W.C; P.hit = W.hit;
+    P.A = W.A; P.B = W.B; P.L = W.L; P.Tz = W.Tz; P.hit = W.hit;
     P.queue[0] = W.q0; P.queue[1] = W.q1;
     P.counts = W.counts;
     Counters* gc = W.counters;
@@ -2148,7 +2193,7 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
         uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
         // Paths per batch.  Every bounce of a batch is one launch whose last rays set its duration (a few hundred
         // microseconds for the slowest line of a deep tree, however few lines are left), so batches should be as
-        // large as memory allows: 76 bytes of HBM per path slot.  Default: the whole call in one batch, up to
+        // large as memory allows: 80 bytes of HBM per path slot.  Default: the whole call in one batch, up to
         // 2^30 paths (82 GB) and half of the device's memory; halved again for as long as the allocation fails.
         uint64_t maxPaths = p->max_batch_paths;
         if (const char* text = std::getenv("RT_AMD_BATCH_PATHS")) maxPaths = std::max<uint64_t>(1, std::strtoull(text, nullptr, 10));
@@ -2157,7 +2202,7 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
             size_t freeBytes = 0, totalBytes = 0;
             maxPaths = 1ull << 30;
             if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && totalBytes > 0)
-                maxPaths = std::min<uint64_t>(maxPaths, std::max<uint64_t>(16ull << 20, totalBytes / 2 / 76));
+                maxPaths = std::min<uint64_t>(maxPaths, std::max<uint64_t>(16ull << 20, totalBytes / 2 / 80));
         }
         Workspace& W = s->ws;
         uint32_t spb = 0;
@@ -2171,7 +2216,8 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
             void* ptr = nullptr;
             hipError_t e = hipMalloc(&ptr, batchPaths * 16); W.A = static_cast<float4*>(ptr); ptr = nullptr;
             if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 16); W.B = static_cast<float4*>(ptr); ptr = nullptr; }
-            if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 16); W.C = static_cast<float4*>(ptr); ptr = nullptr; }
+            if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 16); W.L = static_cast<float4*>(ptr); ptr = nullptr; }
+            if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 4); W.Tz = static_cast<float*>(ptr); ptr = nullptr; }
             if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 16); W.hit = static_cast<float4*>(ptr); ptr = nullptr; }
             if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 4); W.q0 = static_cast<uint32_t*>(ptr); ptr = nullptr; }
             if (e == hipSuccess) { e = hipMalloc(&ptr, batchPaths * 4); W.q1 = static_cast<uint32_t*>(ptr); ptr = nullptr; }
