@@ -55,7 +55,8 @@ int fail(int code, const std::string& msg) {
 //   index > 0 : interior; children are nodes[index] (negative side) and nodes[index+1] (positive);
 //               aux = division axis (bits 0-1), negative child empty (bit 2), positive child empty (bit 3).  The split plane is the centre of the node's own box on that
 //               axis, which is how BSPTree computes positiveChild.box.min[axis] (src/bsp.hpp:256-274).
-//   index < 0 : leaf; triangles are leafTris[-index-1 .. -index-1+aux)
+//   index < 0 : leaf; triangles are leafTris[-index-1 .. -index-1+count); aux = count (bits 0-10) and a cone around the
+//               triangles' normals (bits 11-30, see coneAllBackFacing), or bit 31 and the count in a leaf of 2048 or more
 //   index == 0: empty
 // Leaf triangle record, 48 bytes = three float4, stored once per (leaf, triangle) reference so a leaf's
 // triangles are contiguous:  {n.x n.y n.z v1.x} {v1.y v1.z e13.x e13.y} {e13.z e12.x e12.y e12.z}.
@@ -200,6 +201,36 @@ __device__ __forceinline__ bool originInsideRule(int filterBits, float mu, V3 o,
     bool const inside = o.x >= lo.x && o.x <= hi.x && o.y >= lo.y && o.y <= hi.y && o.z >= lo.z && o.z <= hi.z;
     bool const onPlane = o.x == lo.x || o.x == hi.x || o.y == lo.y || o.y == hi.y || o.z == lo.z || o.z == hi.z;
     return inside && mu < INFINITY && (onPlane || (filterBits & 4) != 0);
+}
+
+// ---- leaf normal cones ---------------------------------------------------------------------------------
+// The triangle test rejects a triangle whose normal does not face the line's origin (Surfaces::FRONT_ONLY:
+// normal . direction <= -1e-6, src/geometry.hpp:129-131).  44 % of the leaves a path segment visits hold no triangle
+// that passes it.  A leaf record therefore carries a cone that contains the normals of all its triangles -- axis as a
+// 7+7-bit octahedral code, and q/63 >= sin(spread + 0.002 rad), rounded up, spread being the largest angle between the
+// DECODED axis and a normal -- and the leaf is skipped when axis . direction >= (q/63) |axis| |direction|: then every
+// normal makes an angle of at most 90 degrees - 0.002 rad with the direction, so normal . direction >= 0.002 |normal|
+// |direction|, which no rounding of the fused dot product (relative error below 2^-22) brings down to -1e-6: each
+// triangle of the leaf would have been rejected one by one.  Kernels that count work test every triangle as the
+// reference does and count a disagreement with the cone as an error (rt_stats.box_filter_errors).
+__device__ __forceinline__ uint32_t leafTriCount(uint32_t aux) { return (aux & 0x80000000u) ? (aux & 0x7FFFFFFFu) : (aux & 0x7FFu); }
+
+__device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
+    uint32_t const q = (aux >> 11) & 0x3Fu;
+    if ((aux & 0x80000000u) != 0u || q == 0u) return false;
+    float px = static_cast<float>((aux >> 17) & 0x7Fu) * (2.0f / 127.0f) - 1.0f;
+    float py = static_cast<float>((aux >> 24) & 0x7Fu) * (2.0f / 127.0f) - 1.0f;
+    float const pz = 1.0f - fabsf(px) - fabsf(py);
+    if (pz < 0.0f) {
+        float const ox = (1.0f - fabsf(py)) * (px >= 0.0f ? 1.0f : -1.0f);
+        float const oy = (1.0f - fabsf(px)) * (py >= 0.0f ? 1.0f : -1.0f);
+        px = ox; py = oy;
+    }
+    float const thr = static_cast<float>(q) * (1.0f / 63.0f);
+    float const ad = px * d.x + py * d.y + pz * d.z;
+    float const aa = px * px + py * py + pz * pz;
+    float const dd = d.x * d.x + d.y * d.y + d.z * d.z;
+    return ad > 0.0f && ad * ad >= thr * thr * aa * dd;
 }
 
 // Diagnostic build only (-DRT_DIAG, make diag): per-phase cycle and lane-occupancy tallies of traceStream.
@@ -395,7 +426,10 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             }
             else cur = NONE;
             if (meets && index < 0) {
-                if (pend1 == NONE) pend1 = here; else if (pend2 == NONE) pend2 = here; else pend3 = here;
+                // a leaf whose triangles all face away from the origin needs no scan (coneAllBackFacing)
+                if (COUNT || !FRONT_ONLY || !coneAllBackFacing(aux, d)) {
+                    if (pend1 == NONE) pend1 = here; else if (pend2 == NONE) pend2 = here; else pend3 = here;
+                }
                 if (COUNT) break;
             }
         }
@@ -403,13 +437,15 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
         DIAG_T(t2);
         DIAG_ADD(1, t2 - t1);
         uint32_t leafFirst = 0, leafCount = 0;
+        bool coneSkips = false;           // counting kernels: the cone says "skip", to be checked against every triangle
         V3 lo = mk(0.0f, 0.0f, 0.0f), hi = lo;
         if (pend1 != NONE) {
             float4 const q0 = S.nodes[2 * pend1];
             float4 const q1 = S.nodes[2 * pend1 + 1];
             lo = mk(q0.x, q0.y, q0.z); hi = mk(q0.w, q1.x, q1.y);
             leafFirst = static_cast<uint32_t>(-(__float_as_int(q1.z) + 1));
-            leafCount = __float_as_uint(q1.w);
+            leafCount = leafTriCount(__float_as_uint(q1.w));
+            coneSkips = COUNT && FRONT_ONLY && coneAllBackFacing(__float_as_uint(q1.w), d);
             pend1 = pend2; pend2 = pend3; pend3 = NONE;
         }
 
@@ -440,6 +476,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                     float const negDet = dotF(nrm, d);
                     bool const detOk = FRONT_ONLY ? (negDet <= -1e-6f) : (fabsf(negDet) >= 1e-6f);
                     if (!detOk) continue;
+                    if (COUNT && coneSkips) c.boxFilterErrors++;
                     if (FRONT_ONLY) {
                         float4 const b = tp[1], e = tp[2];
                         V3 const v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x), e12 = mk(e.y, e.z, e.w);
@@ -1602,6 +1639,62 @@ int gatherTriNormals(const rt_scene_desc* D, const char* who, std::vector<float>
     return RT_OK;
 }
 
+// Cone code of a leaf (bits 11-30 of the leaf record's aux word; 0: none), from the normals that head the leaf's triangle
+// records (12 floats each).  The axis is the 7+7-bit octahedral code nearest to the mean unit normal; the threshold is
+// derived from the axis AS THE KERNEL DECODES IT, with 0.002 rad to spare, and rounded up to a multiple of 1/63.
+uint32_t leafCone(const float* records, uint32_t count) {
+    double mean[3] = {0.0, 0.0, 0.0};
+    uint32_t used = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        float const* n = records + 12 * static_cast<size_t>(i);
+        double const len = std::sqrt(double(n[0]) * n[0] + double(n[1]) * n[1] + double(n[2]) * n[2]);
+        if (!(len > 0.0) || !(len < 1e300)) {
+            if (len == 0.0) continue;            // a zero normal fails the facing test whatever the direction
+            return 0u;                           // NaN or infinite normal: no cone
+        }
+        for (int k = 0; k < 3; ++k) mean[k] += n[k] / len;
+        ++used;
+    }
+    double const meanLen = std::sqrt(mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
+    if (used == 0 || !(meanLen > 1e-6)) return 0u;
+    double const a[3] = {mean[0] / meanLen, mean[1] / meanLen, mean[2] / meanLen};
+    double const l1 = std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]);
+    double px = a[0] / l1, py = a[1] / l1;
+    if (a[2] < 0.0) {
+        double const ox = (1.0 - std::fabs(py)) * (px >= 0.0 ? 1.0 : -1.0), oy = (1.0 - std::fabs(px)) * (py >= 0.0 ? 1.0 : -1.0);
+        px = ox; py = oy;
+    }
+    uint32_t const u = static_cast<uint32_t>(std::min(127.0, std::max(0.0, std::floor((px * 0.5 + 0.5) * 127.0 + 0.5))));
+    uint32_t const v = static_cast<uint32_t>(std::min(127.0, std::max(0.0, std::floor((py * 0.5 + 0.5) * 127.0 + 0.5))));
+    // decode exactly as the kernel does
+    float fx = static_cast<float>(u) * (2.0f / 127.0f) - 1.0f;
+    float fy = static_cast<float>(v) * (2.0f / 127.0f) - 1.0f;
+    float const fz = 1.0f - std::fabs(fx) - std::fabs(fy);
+    if (fz < 0.0f) {
+        float const ox = (1.0f - std::fabs(fy)) * (fx >= 0.0f ? 1.0f : -1.0f);
+        float const oy = (1.0f - std::fabs(fx)) * (fy >= 0.0f ? 1.0f : -1.0f);
+        fx = ox; fy = oy;
+    }
+    double const axisLen = std::sqrt(double(fx) * fx + double(fy) * fy + double(fz) * fz);
+    if (!(axisLen > 0.0)) return 0u;
+    double spread = 0.0;
+    for (uint32_t i = 0; i < count; ++i) {
+        float const* n = records + 12 * static_cast<size_t>(i);
+        double const len = std::sqrt(double(n[0]) * n[0] + double(n[1]) * n[1] + double(n[2]) * n[2]);
+        if (len == 0.0) continue;
+        double const c = (n[0] * double(fx) + n[1] * double(fy) + n[2] * double(fz)) / (len * axisLen);
+        spread = std::max(spread, std::acos(std::min(1.0, std::max(-1.0, c))));
+    }
+    double const angle = spread + 0.002;
+    if (!(angle <= 1.53)) return 0u;
+    double const needed = std::sin(angle);
+    uint32_t q = static_cast<uint32_t>(std::ceil(needed * 63.0));
+    if (q == 0u) q = 1u;
+    while (q <= 63u && double(static_cast<float>(q) * (1.0f / 63.0f)) < needed) ++q;
+    if (q > 63u) return 0u;
+    return (q << 11) | (u << 17) | (v << 24);
+}
+
 // One 48-byte shading record: {model, vn1.xyz} {vn2.xyz, vn3.x} {vn3.yz, 0, 0}.
 void shadeRecord(float* rec, uint32_t model, const float* normals9) {
     std::memcpy(rec, &model, 4);
@@ -1707,6 +1800,18 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
         uint32_t const ids[4] = {ref.mesh, ref.tri, gtri, 0u};
         std::memcpy(leafIds.data() + 4 * static_cast<size_t>(r), ids, 16);
     }
+    // ---- leaf normal cones (see coneAllBackFacing) ----------------------------------------------------
+    unsigned long long leavesSeen = 0, leavesWithCone = 0, thresholdSum = 0;
+    for (HNode& node : nodes) {
+        if (node.index >= 0) continue;
+        uint32_t const first = static_cast<uint32_t>(-(node.index + 1)), leafCount = node.aux;
+        node.aux = leafCount >= 2048u ? (0x80000000u | leafCount) : (leafCount | leafCone(leafTris.data() + 12 * static_cast<size_t>(first), leafCount));
+        ++leavesSeen;
+        if ((node.aux >> 11) != 0u && (node.aux & 0x80000000u) == 0u) { ++leavesWithCone; thresholdSum += (node.aux >> 11) & 0x3Fu; }
+    }
+    if (std::getenv("RT_AMD_DEBUG"))
+        std::fprintf(stderr, "rt_amd: %llu of %llu leaves carry a normal cone, mean threshold %.3f\n", leavesWithCone, leavesSeen,
+                     leavesWithCone ? double(thresholdSum) / 63.0 / double(leavesWithCone) : 0.0);
     std::vector<float> triNormals;
     {
         int const rc = gatherTriNormals(D, "rt_scene_create", triNormals);
