@@ -161,9 +161,10 @@ typedef struct {
     double ms_total;              /* whole call, host clock, after the final sync */
     double ms_raygen, ms_trace, ms_shade, ms_accumulate;          /* RT_FLAG_PROFILE_KERNELS only */
     uint32_t trace_launches, batches;
-    /* RT_FLAG_COUNT_WORK only: box tests the conservative slab filter left to the exact six-face test,
-     * and filter decisions that disagreed with the exact test (the counting kernels evaluate both;
-     * anything but 0 is a bug). */
+    /* RT_FLAG_COUNT_WORK only: box tests the conservative slab filter left to the exact six-face test, and
+     * decisions of the kernels' conservative shortcuts that disagreed with the exact evaluation (the counting
+     * kernels evaluate both: the slab filter against the six-face test on every box, the leaf normal cone against
+     * the facing test of every triangle; anything but 0 is a bug). */
     uint64_t box_exact_fallbacks, box_filter_errors;
 } rt_stats;
 
