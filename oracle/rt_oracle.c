@@ -824,12 +824,12 @@ static int bvh_nearest_hit(const orc_scene* s, v3 o, v3 d, float tMin, int front
                 if (t[k] < INFINITY) ++nHit;
             }
             if (nHit == 0) { cur = sp > 0 ? stack[--sp] : NONE; continue; }
-            /* position in ascending (entry, slot) order */
+            /* position in ascending (entry measured from `lower`, slot) order */
             int pos[4];
             for (int k = 0; k < 4; ++k) {
                 pos[k] = 0;
                 for (int j = 0; j < 4; ++j)
-                    if (j != k && (t[j] < t[k] || (t[j] == t[k] && j < k))) ++pos[k];
+                    if (j != k && ((t[j] - lower) < (t[k] - lower) || ((t[j] - lower) == (t[k] - lower) && j < k))) ++pos[k];
             }
             for (int k = 0; k < 4; ++k) {
                 if (pos[k] == 0) cur = child[k];

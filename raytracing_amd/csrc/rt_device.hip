@@ -700,7 +700,12 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             uint32_t const c0 = ne.c0, c1 = ne.c1, c2 = ne.c2, c3 = ne.c3;
             float const t0 = ne.t0, t1 = ne.t1, t2 = ne.t2, t3 = ne.t3;
             if (COUNT) { c.inodeVisits++; c.boxTests += (c0 != NONE) + (c1 != NONE) + (c2 != NONE) + (c3 != NONE); }
-            int const nHit = (t0 < INFINITY) + (t1 < INFINITY) + (t2 < INFINITY) + (t3 < INFINITY);
+            // Order keys: an entry parameter measured from `lower` is never negative, so its bit pattern (sign cleared: -0)
+            // orders like its value and "a < b" is the sign of a - b: no compare-and-select chains.
+            uint32_t const b0 = __float_as_uint(t0 - lower) & 0x7FFFFFFFu, b1 = __float_as_uint(t1 - lower) & 0x7FFFFFFFu,
+                           b2 = __float_as_uint(t2 - lower) & 0x7FFFFFFFu, b3 = __float_as_uint(t3 - lower) & 0x7FFFFFFFu;
+            int const nHit = static_cast<int>(((b0 - 0x7F800000u) >> 31) + ((b1 - 0x7F800000u) >> 31) + ((b2 - 0x7F800000u) >> 31)
+                                              + ((b3 - 0x7F800000u) >> 31));
             if (nHit == 0) {
                 if (sp > 0) {
                     --sp;
@@ -711,10 +716,12 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             }
             else {
                 // position of each child in ascending (entry, slot) order; children that are missed (+inf) come last
-                int const k0 = (t1 < t0) + (t2 < t0) + (t3 < t0);
-                int const k1 = (t0 <= t1) + (t2 < t1) + (t3 < t1);
-                int const k2 = (t0 <= t2) + (t1 <= t2) + (t3 < t2);
-                int const k3 = (t0 <= t3) + (t1 <= t3) + (t2 <= t3);
+                uint32_t const l10 = (b1 - b0) >> 31, l20 = (b2 - b0) >> 31, l30 = (b3 - b0) >> 31, l21 = (b2 - b1) >> 31,
+                               l31 = (b3 - b1) >> 31, l32 = (b3 - b2) >> 31;          // lij: child i enters before child j
+                int const k0 = static_cast<int>(l10 + l20 + l30);
+                int const k1 = static_cast<int>(1u - l10 + l21 + l31);
+                int const k2 = static_cast<int>(2u - l20 - l21 + l32);
+                int const k3 = static_cast<int>(3u - l30 - l31 - l32);
                 // the nearest becomes current, the other hit children go on the stack, farthest lowest
                 // Unconditional stores when the LDS part of the stack has room: a child that is not deferred (the
                 // nearest, or one the line misses) is written to the first free slot above the new top, where it
@@ -796,7 +803,12 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
             uint32_t const c0 = ne.c0, c1 = ne.c1, c2 = ne.c2, c3 = ne.c3;
             float const t0 = ne.t0, t1 = ne.t1, t2 = ne.t2, t3 = ne.t3;
             if (COUNT) { c.inodeVisits++; c.boxTests += (c0 != NONE) + (c1 != NONE) + (c2 != NONE) + (c3 != NONE); }
-            int const nHit = (t0 < INFINITY) + (t1 < INFINITY) + (t2 < INFINITY) + (t3 < INFINITY);
+            // Order keys: an entry parameter measured from `lower` is never negative, so its bit pattern (sign cleared: -0)
+            // orders like its value and "a < b" is the sign of a - b: no compare-and-select chains.
+            uint32_t const b0 = __float_as_uint(t0 - lower) & 0x7FFFFFFFu, b1 = __float_as_uint(t1 - lower) & 0x7FFFFFFFu,
+                           b2 = __float_as_uint(t2 - lower) & 0x7FFFFFFFu, b3 = __float_as_uint(t3 - lower) & 0x7FFFFFFFu;
+            int const nHit = static_cast<int>(((b0 - 0x7F800000u) >> 31) + ((b1 - 0x7F800000u) >> 31) + ((b2 - 0x7F800000u) >> 31)
+                                              + ((b3 - 0x7F800000u) >> 31));
             if (nHit == 0) {
                 if (sp > 0) {
                     --sp;
@@ -807,10 +819,12 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
                 continue;
             }
             // position of each child in ascending (entry, slot) order; children that are missed (+inf) come last
-            int const k0 = (t1 < t0) + (t2 < t0) + (t3 < t0);
-            int const k1 = (t0 <= t1) + (t2 < t1) + (t3 < t1);
-            int const k2 = (t0 <= t2) + (t1 <= t2) + (t3 < t2);
-            int const k3 = (t0 <= t3) + (t1 <= t3) + (t2 <= t3);
+            uint32_t const l10 = (b1 - b0) >> 31, l20 = (b2 - b0) >> 31, l30 = (b3 - b0) >> 31, l21 = (b2 - b1) >> 31,
+                           l31 = (b3 - b1) >> 31, l32 = (b3 - b2) >> 31;          // lij: child i enters before child j
+            int const k0 = static_cast<int>(l10 + l20 + l30);
+            int const k1 = static_cast<int>(1u - l10 + l21 + l31);
+            int const k2 = static_cast<int>(2u - l20 - l21 + l32);
+            int const k3 = static_cast<int>(3u - l30 - l31 - l32);
             // the nearest becomes current, the other hit children go on the stack, farthest lowest
             // Unconditional stores when the LDS part of the stack has room: a child that is not deferred (the
             // nearest, or one the line misses) is written to the first free slot above the new top, where it
