@@ -3,9 +3,16 @@
  * Nothing in the product (raytracing_amd/, include/) includes, links or calls this library.  It is the
  * checker used by tests/, by __graft_entry__.smoke() and by the cpu_baseline leg of bench.py.
  *
- * Parity status: PINNED.  Every function below is checked bit-for-bit against the reference's own code
- * (compiled by oracle/build_ref.sh into oracle/_ref/libref.so) in tests/test_oracle_vs_ref.py, and
- * against golden vectors generated from that build (tests/golden/, script oracle/make_golden.py).
+ * Parity status: PINNED.  Every function that restates the reference is checked bit-for-bit against the
+ * reference's own code (compiled by oracle/build_ref.sh into oracle/_ref/libref.so) in
+ * tests/test_oracle_vs_ref.py, and against golden vectors generated from that build (tests/golden/, script
+ * oracle/make_golden.py).
+ *
+ * Three parts restate extensions of the product that the reference does not have, so that the GPU can be checked
+ * bit for bit against them too; they are marked where they are declared: Russian roulette and per-lobe sampling in
+ * device-mode rendering (pinned statistically: same converged image as the reference's estimator), and the
+ * traversal of the product's bounding volume hierarchy (pinned by orc_intersect_brute, a scan of all triangles
+ * with the reference's own triangle test, and by its agreement with the BSP traversal).
  *
  * All arithmetic is IEEE binary32 with -ffp-contract=off; fused multiply-adds appear only where the
  * reference uses FMA intrinsics (src/utility/vectorised.hpp:405-481).
