@@ -55,8 +55,8 @@ int fail(int code, const std::string& msg) {
 //   index > 0 : interior; children are nodes[index] (negative side) and nodes[index+1] (positive);
 //               aux = division axis (bits 0-1), negative child empty (bit 2), positive child empty (bit 3).  The split plane is the centre of the node's own box on that
 //               axis, which is how BSPTree computes positiveChild.box.min[axis] (src/bsp.hpp:256-274).
-//   index < 0 : leaf; triangles are leafTris[-index-1 .. -index-1+count); aux = count (bits 0-10) and a cone around the
-//               triangles' normals (bits 11-30, see coneAllBackFacing), or bit 31 and the count in a leaf of 2048 or more
+//   index < 0 : leaf; triangles are leafTris[-index-1 .. -index-1+count); aux = count (bits 0-7) and a cone around the
+//               triangles' normals (bits 8-30, see coneAllBackFacing), or bit 31 and the count in a leaf of 256 or more
 //   index == 0: empty
 // Leaf triangle record, 48 bytes = three float4, stored once per (leaf, triangle) reference so a leaf's
 // triangles are contiguous:  {n.x n.y n.z v1.x} {v1.y v1.z e13.x e13.y} {e13.z e12.x e12.y e12.z}.
@@ -206,31 +206,27 @@ __device__ __forceinline__ bool originInsideRule(int filterBits, float mu, V3 o,
 // ---- leaf normal cones ---------------------------------------------------------------------------------
 // The triangle test rejects a triangle whose normal does not face the line's origin (Surfaces::FRONT_ONLY:
 // normal . direction <= -1e-6, src/geometry.hpp:129-131).  44 % of the leaves a path segment visits hold no triangle
-// that passes it.  A leaf record therefore carries a cone that contains the normals of all its triangles -- axis as a
-// 7+7-bit octahedral code, and q/63 >= sin(spread + 0.002 rad), rounded up, spread being the largest angle between the
-// DECODED axis and a normal -- and the leaf is skipped when axis . direction >= (q/63) |axis| |direction|: then every
-// normal makes an angle of at most 90 degrees - 0.002 rad with the direction, so normal . direction >= 0.002 |normal|
-// |direction|, which no rounding of the fused dot product (relative error below 2^-22) brings down to -1e-6: each
-// triangle of the leaf would have been rejected one by one.  Kernels that count work test every triangle as the
-// reference does and count a disagreement with the cone as an error (rt_stats.box_filter_errors).
-__device__ __forceinline__ uint32_t leafTriCount(uint32_t aux) { return (aux & 0x80000000u) ? (aux & 0x7FFFFFFFu) : (aux & 0x7FFu); }
+// that passes it.  A leaf record therefore carries a cone that contains the normals of all its triangles -- the axis A
+// as three 6-bit signed integers (a point near the sphere of radius 31), and an integer q >= |A| sin(spread + 0.002 rad),
+// rounded up, spread being the largest angle between A and a normal -- and the leaf is skipped when
+// A . direction >= q |direction|: then every normal makes an angle of at most 90 degrees - 0.002 rad with the direction,
+// so normal . direction >= 0.002 |normal| |direction|, which no rounding of the fused dot product (relative error below
+// 2^-22) brings down to -1e-6: each triangle of the leaf would have been rejected one by one.  A leaf without a cone has
+// A = 0, which never passes.  Integer fields decode in two instructions each, which matters: the test runs in the walking
+// loop, for the few lanes of a wave that stand on a leaf.  Kernels that count work test every triangle as the reference
+// does and count a disagreement with the cone as an error (rt_stats.box_filter_errors).
+//   aux of a leaf: count (bits 0-7), q (8-12), A.z (13-18), A.y (19-24), A.x (25-30); bit 31: 256 triangles or more, the
+//   count in bits 0-30 and no cone.
+__device__ __forceinline__ uint32_t leafTriCount(uint32_t aux) { return (aux & 0x80000000u) ? (aux & 0x7FFFFFFFu) : (aux & 0xFFu); }
 
 __device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
-    uint32_t const q = (aux >> 11) & 0x3Fu;
-    if ((aux & 0x80000000u) != 0u || q == 0u) return false;
-    float px = static_cast<float>((aux >> 17) & 0x7Fu) * (2.0f / 127.0f) - 1.0f;
-    float py = static_cast<float>((aux >> 24) & 0x7Fu) * (2.0f / 127.0f) - 1.0f;
-    float const pz = 1.0f - fabsf(px) - fabsf(py);
-    if (pz < 0.0f) {
-        float const ox = (1.0f - fabsf(py)) * (px >= 0.0f ? 1.0f : -1.0f);
-        float const oy = (1.0f - fabsf(px)) * (py >= 0.0f ? 1.0f : -1.0f);
-        px = ox; py = oy;
-    }
-    float const thr = static_cast<float>(q) * (1.0f / 63.0f);
-    float const ad = px * d.x + py * d.y + pz * d.z;
-    float const aa = px * px + py * py + pz * pz;
-    float const dd = d.x * d.x + d.y * d.y + d.z * d.z;
-    return ad > 0.0f && ad * ad >= thr * thr * aa * dd;
+    float const ax = static_cast<float>(static_cast<int32_t>(aux << 1) >> 26);
+    float const ay = static_cast<float>(static_cast<int32_t>(aux << 7) >> 26);
+    float const az = static_cast<float>(static_cast<int32_t>(aux << 13) >> 26);
+    float const q = static_cast<float>((aux >> 8) & 0x1Fu);
+    float const ad = __fmaf_rn(ax, d.x, __fmaf_rn(ay, d.y, az * d.z));
+    float const dd = __fmaf_rn(d.x, d.x, __fmaf_rn(d.y, d.y, d.z * d.z));
+    return static_cast<int32_t>(aux) >= 0 && ad > 0.0f && ad * ad >= (q * q) * dd;
 }
 
 // Diagnostic build only (-DRT_DIAG, make diag): per-phase cycle and lane-occupancy tallies of traceStream.
@@ -1653,9 +1649,9 @@ int gatherTriNormals(const rt_scene_desc* D, const char* who, std::vector<float>
     return RT_OK;
 }
 
-// Cone code of a leaf (bits 11-30 of the leaf record's aux word; 0: none), from the normals that head the leaf's triangle
-// records (12 floats each).  The axis is the 7+7-bit octahedral code nearest to the mean unit normal; the threshold is
-// derived from the axis AS THE KERNEL DECODES IT, with 0.002 rad to spare, and rounded up to a multiple of 1/63.
+// Cone code of a leaf (bits 8-30 of the leaf record's aux word; 0: none), from the normals that head the leaf's triangle
+// records (12 floats each).  The axis is the integer point nearest to 31 times the mean unit normal; the threshold is
+// derived from that integer axis, with 0.002 rad to spare, and rounded up to an integer.
 uint32_t leafCone(const float* records, uint32_t count) {
     double mean[3] = {0.0, 0.0, 0.0};
     uint32_t used = 0;
@@ -1671,42 +1667,26 @@ uint32_t leafCone(const float* records, uint32_t count) {
     }
     double const meanLen = std::sqrt(mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
     if (used == 0 || !(meanLen > 1e-6)) return 0u;
-    double const a[3] = {mean[0] / meanLen, mean[1] / meanLen, mean[2] / meanLen};
-    double const l1 = std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]);
-    double px = a[0] / l1, py = a[1] / l1;
-    if (a[2] < 0.0) {
-        double const ox = (1.0 - std::fabs(py)) * (px >= 0.0 ? 1.0 : -1.0), oy = (1.0 - std::fabs(px)) * (py >= 0.0 ? 1.0 : -1.0);
-        px = ox; py = oy;
-    }
-    uint32_t const u = static_cast<uint32_t>(std::min(127.0, std::max(0.0, std::floor((px * 0.5 + 0.5) * 127.0 + 0.5))));
-    uint32_t const v = static_cast<uint32_t>(std::min(127.0, std::max(0.0, std::floor((py * 0.5 + 0.5) * 127.0 + 0.5))));
-    // decode exactly as the kernel does
-    float fx = static_cast<float>(u) * (2.0f / 127.0f) - 1.0f;
-    float fy = static_cast<float>(v) * (2.0f / 127.0f) - 1.0f;
-    float const fz = 1.0f - std::fabs(fx) - std::fabs(fy);
-    if (fz < 0.0f) {
-        float const ox = (1.0f - std::fabs(fy)) * (fx >= 0.0f ? 1.0f : -1.0f);
-        float const oy = (1.0f - std::fabs(fx)) * (fy >= 0.0f ? 1.0f : -1.0f);
-        fx = ox; fy = oy;
-    }
-    double const axisLen = std::sqrt(double(fx) * fx + double(fy) * fy + double(fz) * fz);
+    int axis[3];
+    for (int k = 0; k < 3; ++k)
+        axis[k] = static_cast<int>(std::min(31.0, std::max(-31.0, std::floor(mean[k] / meanLen * 31.0 + 0.5))));
+    double const axisLen = std::sqrt(double(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]));
     if (!(axisLen > 0.0)) return 0u;
     double spread = 0.0;
     for (uint32_t i = 0; i < count; ++i) {
         float const* n = records + 12 * static_cast<size_t>(i);
         double const len = std::sqrt(double(n[0]) * n[0] + double(n[1]) * n[1] + double(n[2]) * n[2]);
         if (len == 0.0) continue;
-        double const c = (n[0] * double(fx) + n[1] * double(fy) + n[2] * double(fz)) / (len * axisLen);
+        double const c = (n[0] * double(axis[0]) + n[1] * double(axis[1]) + n[2] * double(axis[2])) / (len * axisLen);
         spread = std::max(spread, std::acos(std::min(1.0, std::max(-1.0, c))));
     }
     double const angle = spread + 0.002;
     if (!(angle <= 1.53)) return 0u;
-    double const needed = std::sin(angle);
-    uint32_t q = static_cast<uint32_t>(std::ceil(needed * 63.0));
-    if (q == 0u) q = 1u;
-    while (q <= 63u && double(static_cast<float>(q) * (1.0f / 63.0f)) < needed) ++q;
-    if (q > 63u) return 0u;
-    return (q << 11) | (u << 17) | (v << 24);
+    double const needed = std::sin(angle) * axisLen * (1.0 + 1e-6);
+    uint32_t const q = std::max(1u, static_cast<uint32_t>(std::ceil(needed)));
+    if (q > 31u) return 0u;
+    return (q << 8) | ((static_cast<uint32_t>(axis[2]) & 0x3Fu) << 13) | ((static_cast<uint32_t>(axis[1]) & 0x3Fu) << 19)
+         | ((static_cast<uint32_t>(axis[0]) & 0x3Fu) << 25);
 }
 
 // One 48-byte shading record: {model, vn1.xyz} {vn2.xyz, vn3.x} {vn3.yz, 0, 0}.
@@ -1819,13 +1799,13 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     for (HNode& node : nodes) {
         if (node.index >= 0) continue;
         uint32_t const first = static_cast<uint32_t>(-(node.index + 1)), leafCount = node.aux;
-        node.aux = leafCount >= 2048u ? (0x80000000u | leafCount) : (leafCount | leafCone(leafTris.data() + 12 * static_cast<size_t>(first), leafCount));
+        node.aux = leafCount >= 256u ? (0x80000000u | leafCount) : (leafCount | leafCone(leafTris.data() + 12 * static_cast<size_t>(first), leafCount));
         ++leavesSeen;
-        if ((node.aux >> 11) != 0u && (node.aux & 0x80000000u) == 0u) { ++leavesWithCone; thresholdSum += (node.aux >> 11) & 0x3Fu; }
+        if ((node.aux >> 8) != 0u && (node.aux & 0x80000000u) == 0u) { ++leavesWithCone; thresholdSum += (node.aux >> 8) & 0x1Fu; }
     }
     if (std::getenv("RT_AMD_DEBUG"))
         std::fprintf(stderr, "rt_amd: %llu of %llu leaves carry a normal cone, mean threshold %.3f\n", leavesWithCone, leavesSeen,
-                     leavesWithCone ? double(thresholdSum) / 63.0 / double(leavesWithCone) : 0.0);
+                     leavesWithCone ? double(thresholdSum) / 31.0 / double(leavesWithCone) : 0.0);
     std::vector<float> triNormals;
     {
         int const rc = gatherTriNormals(D, "rt_scene_create", triNormals);
