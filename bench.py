@@ -135,6 +135,10 @@ def roofline(workload, work, seg_per_launch, launch_ms, trace_share, accel="bsp"
         d = pmc.get("k_trace_per_segment", {})
         peaks = pmc.get("peaks_unprofiled", {})
         out["counters_file"] = os.path.relpath(pmc_file, ROOT)
+        sq = next((v.get("sq", {}) for k, v in pmc.get("kernels", {}).items() if k.startswith(d.get("kernel", "k_trace"))), {})
+        if sq.get("SQ_BUSY_CU_CYCLES"):
+            # both counters tick once per four clocks; their ratio is the mean number of waves resident per SIMD
+            out["occupancy_waves_per_simd"] = sq["SQ_WAVE_CYCLES"] / sq["SQ_BUSY_CU_CYCLES"]
         if "hbm_bytes_per_segment" in d:
             traffic = d["hbm_bytes_per_segment"] * seg_per_launch
             a = d["hbm_bytes_per_segment"] * seg_per_s / 1e9
