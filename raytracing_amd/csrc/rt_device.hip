@@ -234,7 +234,10 @@ __device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
 __device__ unsigned long long g_diag[16];
 #define DIAG_T(var) unsigned long long var = clock64()
 #define DIAG_ADD(slot, value) diag[slot] += (value)
-#define DIAG_LANES(iterSlot, laneSlot) do { diag[iterSlot] += 1; diag[laneSlot] += __popcll(__ballot(true)); } while (0)
+// once per wave iteration, by the first lane that is here: iterations and the lanes taking part
+#define DIAG_LANES(iterSlot, laneSlot) do { unsigned long long const here_ = __ballot(true); \
+    if ((threadIdx.x & 63) == static_cast<unsigned>(__ffsll(static_cast<long long>(here_)) - 1)) { \
+        atomicAdd(&g_diag[iterSlot], 1ull); atomicAdd(&g_diag[laneSlot], static_cast<unsigned long long>(__popcll(here_))); } } while (0)
 // once per wave, whichever lanes are here
 #define DIAG_WAVE(slot) do { if ((threadIdx.x & 63) == static_cast<unsigned>(__ffsll(static_cast<long long>(__ballot(true))) - 1)) atomicAdd(&g_diag[slot], 1ull); } while (0)
 #else
@@ -528,7 +531,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     }
 #ifdef RT_DIAG
     if (lane == 0)
-        for (int k = 0; k < 14; ++k) if (k != 5 && diag[k]) atomicAdd(&g_diag[k], diag[k]);
+        for (int k = 0; k < 14; ++k) if ((k < 5 || k > 11) && diag[k]) atomicAdd(&g_diag[k], diag[k]);
 #endif
 }
 
