@@ -119,7 +119,10 @@ typedef struct {
  * lies in the root box (ties: lowest triangle index).  Of the BSP leaf's in-box rule (src/bsp.hpp:82-87) only
  * the root box is left, so the two accelerators can differ on a ray whose hit point rounds to just outside an
  * inner leaf's box and inside no other leaf that holds the triangle: none in 469 000 rays of the built-in
- * scene, a few in 100 000 on large meshes.  The converged image is unchanged. */
+ * scene, a few in 100 000 on large meshes.  The converged image is unchanged.  The hierarchy's box test treats a
+ * direction component below 2^-80 in magnitude as zero (the line as parallel to that axis): harmless for a direction
+ * of ordinary length, where such a component moves the line by nothing over any finite distance, but a direction
+ * that is that short as a whole is outside this accelerator's domain (the BSP path has no such limit). */
 #define RT_FLAG_ACCEL_BVH 8u
 /* Per-lobe sampling, an estimator extension the reference does not have (it draws every continuation direction
  * from the GGX lobe, src/render.hpp:145-167): the GGX half vector with probability pS, a cosine-weighted direction

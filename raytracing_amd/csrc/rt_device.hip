@@ -226,7 +226,9 @@ __device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
     float const q = static_cast<float>((aux >> 8) & 0x1Fu);
     float const ad = __fmaf_rn(ax, d.x, __fmaf_rn(ay, d.y, az * d.z));
     float const dd = __fmaf_rn(d.x, d.x, __fmaf_rn(d.y, d.y, d.z * d.z));
-    return static_cast<int32_t>(aux) >= 0 && ad > 0.0f && ad * ad >= (q * q) * dd;
+    // a direction so long that the squares overflow, or so short that they underflow, decides nothing
+    float const lhs = ad * ad, rhs = (q * q) * dd;
+    return static_cast<int32_t>(aux) >= 0 && ad > 0.0f && lhs >= rhs && lhs < INFINITY && rhs >= 0x1p-100f;
 }
 
 // Diagnostic build only (-DRT_DIAG, make diag): per-phase cycle and lane-occupancy tallies of traceStream.

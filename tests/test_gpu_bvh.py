@@ -90,6 +90,16 @@ def test_axis_parallel_lines_on_the_device(oracle_lib):
             _check_hits(got, f, ids)
             fb, idb = osc.intersect_brute(o, d, 1e-3, front)
             _check_hits(got, fb, idb)
+        # directions of extreme length (squares overflow; below 1e-6 / |normal| nothing can be hit at all)
+        (o, d), _ = _rays(sc, osc, 64, 64, 3000, seed=5)
+        for length in (1e-12, 1e12, 1e19, 3e19, 1e25):
+            dl = (d.astype(np.float64) * length).astype(np.float32)
+            for front in (True, False):
+                got = ds.intersect(o, dl, 0.0, front, use_bvh=True)
+                f, ids = osc.intersect(o, dl, 0.0, front, use_bvh=True)
+                _check_hits(got, f, ids)
+                fb, idb = osc.intersect_brute(o, dl, 0.0, front)
+                _check_hits(got, fb, idb)
     finally:
         ds.close(); osc.close()
 

@@ -168,6 +168,13 @@ def test_intersect_edge_cases(builtin, builtin_oracle):
     dd = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
     f, ids = builtin_oracle.intersect(oo, dd)
     _check_hits(ds.intersect(oo, dd), f, ids)
+    # directions of extreme length: their squares overflow or underflow, which the conservative shortcuts
+    # (slab filter, sign tests, leaf normal cones) must notice and leave to the exact arithmetic
+    for length in (1e-30, 1e-22, 1e-12, 1e12, 1e19, 3e19, 1e25):
+        ds_ = (dd.astype(np.float64) * length).astype(np.float32)
+        for front in (True, False):
+            f, ids = builtin_oracle.intersect(oo, ds_, 0.0, front)
+            _check_hits(ds.intersect(oo, ds_, 0.0, front), f, ids)
 
 
 def test_intersect_device_pointer_form(builtin, builtin_oracle):
