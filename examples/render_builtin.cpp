@@ -58,11 +58,13 @@ double seconds(std::chrono::steady_clock::time_point a, std::chrono::steady_cloc
 }  // namespace
 
 int main(int argcAll, char** argvAll) {
-    // "--bvh" anywhere on the command line: render through the alternative accelerator (RT_FLAG_ACCEL_BVH)
+    // "--bvh" anywhere on the command line: render through the alternative accelerator (RT_FLAG_ACCEL_BVH);
+    // "--gpu-build": build the BSP tree with rt_bsp_build_device (the same tree)
     std::vector<char*> args;
-    bool hierarchy = false;
+    bool hierarchy = false, gpuBuild = false;
     for (int i = 0; i < argcAll; ++i) {
         if (i > 0 && std::string(argvAll[i]) == "--bvh") hierarchy = true;
+        else if (i > 0 && std::string(argvAll[i]) == "--gpu-build") gpuBuild = true;
         else args.push_back(argvAll[i]);
     }
     int const argc = static_cast<int>(args.size());
@@ -102,7 +104,7 @@ int main(int argcAll, char** argvAll) {
 
         auto const t0 = std::chrono::steady_clock::now();
         scene.preprocess();
-        rt::BSPTree const bspTree{scene};
+        rt::BSPTree const bspTree{scene, 0, 48, gpuBuild ? 0 : -1};
         auto const t1 = std::chrono::steady_clock::now();
         std::vector<rt::Vec3> renderBuffer(static_cast<std::size_t>(width) * height);
         rt::RenderData const renderData{width, height, scene.camera.position, scene.pixelToRayTransform(width, height), {bspTree, scene}};

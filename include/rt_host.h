@@ -94,6 +94,14 @@ typedef struct rt_bsp rt_bsp;
 int rt_bsp_build(const float* inst_positions, const uint32_t* model_vertex_begin, const uint32_t* base_tris,
                  const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,
                  const float root_box[6], uint32_t max_leaf_tris, uint32_t max_depth, int threads, rt_bsp** out);
+/* The same tree, array for array, with the per-level work on GPU `device` (the exact triangle/box predicate on every
+ * (node, candidate) pair of a level, prefix sums, order-preserving scatter into leaf lists and the next level's
+ * candidates); the host decides leaf / split / empty per node and numbers the nodes depth-first afterwards.  No
+ * counterpart in the reference, whose constructor (src/bsp.hpp:35-48) is sequential.  At most 2^31 candidate pairs
+ * per level (RT_ERR_LIMIT beyond). */
+int rt_bsp_build_device(const float* inst_positions, const uint32_t* model_vertex_begin, const uint32_t* base_tris,
+                        const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,
+                        const float root_box[6], uint32_t max_leaf_tris, uint32_t max_depth, int device, rt_bsp** out);
 void rt_bsp_destroy(rt_bsp* bsp);
 /* Sizes: inode_count, leaf_count, ref_count, depth, oversized_leaves. */
 void rt_bsp_counts(const rt_bsp* bsp, uint32_t counts[5]);

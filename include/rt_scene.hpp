@@ -168,12 +168,18 @@ struct Scene {                                             // src/scene.hpp:29-4
 
 class BSPTree {                                            // src/bsp.hpp:32-48: built from a preprocessed Scene
 public:
-    explicit BSPTree(Scene const& scene, int threads = 0, std::uint32_t maxDepth = 48) {
-        if (rt_bsp_build(&scene.instantiatedMeshes.vertexPositions.data()->x, scene.instantiatedMeshes.vertexBegin.data(),
-                         scene.meshes.tris.data()->data(), &scene.meshes.triRanges.data()->begin, scene.models.meshes.data(),
-                         static_cast<std::uint32_t>(scene.models.meshes.size()), scene.boundingBox.data(), 32, maxDepth,
-                         threads, &_bsp) != RT_OK)
-            throw std::runtime_error(std::string("BSPTree: ") + rt_last_error());
+    // buildDevice < 0: built on the host with `threads` workers; otherwise the same tree with the per-level work on that GPU
+    explicit BSPTree(Scene const& scene, int threads = 0, std::uint32_t maxDepth = 48, int buildDevice = -1) {
+        float const* positions = &scene.instantiatedMeshes.vertexPositions.data()->x;
+        std::uint32_t const models = static_cast<std::uint32_t>(scene.models.meshes.size());
+        int const rc = buildDevice < 0
+            ? rt_bsp_build(positions, scene.instantiatedMeshes.vertexBegin.data(), scene.meshes.tris.data()->data(),
+                           &scene.meshes.triRanges.data()->begin, scene.models.meshes.data(), models, scene.boundingBox.data(), 32,
+                           maxDepth, threads, &_bsp)
+            : rt_bsp_build_device(positions, scene.instantiatedMeshes.vertexBegin.data(), scene.meshes.tris.data()->data(),
+                                  &scene.meshes.triRanges.data()->begin, scene.models.meshes.data(), models,
+                                  scene.boundingBox.data(), 32, maxDepth, buildDevice, &_bsp);
+        if (rc != RT_OK) throw std::runtime_error(std::string("BSPTree: ") + rt_last_error());
     }
     ~BSPTree() { rt_bsp_destroy(_bsp); }
     BSPTree(BSPTree const&) = delete;

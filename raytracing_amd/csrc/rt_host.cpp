@@ -4,6 +4,7 @@
 // bit-identical to one prepared by the reference (src/main.cpp:191-216).  That requires this file to
 // be compiled with -ffp-contract=off: the reference's scalar code never fuses a multiply with an add.
 #include "rt_host.h"
+#include "rt_bsp_internal.h"
 
 #include <algorithm>
 #include <atomic>
@@ -298,14 +299,6 @@ struct TriGeom {
 
 }  // namespace
 
-struct rt_bsp {
-    float root_box[6];
-    int32_t root_index = 0;
-    std::vector<rt_inode> inodes;
-    std::vector<uint32_t> leaf_first;   // leaf_count + 1
-    std::vector<rt_tri_ref> refs;
-    uint32_t depth = 0, oversized = 0;
-};
 
 namespace {
 

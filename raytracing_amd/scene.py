@@ -230,13 +230,17 @@ class BSPTree:
     MAX_TRIS = 32       # Leaf::MAX_TRIS, src/bsp.hpp:162
 
     def __init__(self, inst_positions, vertex_begin, tris, tri_ranges, instance_meshes, box, max_leaf_tris=32,
-                 max_depth=60, threads=0):
+                 max_depth=60, threads=0, device=None):
+        """device: None builds on the host (rt_bsp_build, `threads` workers); a GPU number builds the same tree
+        with the per-level work on that GPU (rt_bsp_build_device)."""
         L = _lib.lib()
         h = _lib.vp()
         mm = _u32(instance_meshes)
-        _lib.check(L.rt_bsp_build(ptr(_f32(inst_positions)), ptr(_u32(vertex_begin)), ptr(_u32(tris)),
-                                  ptr(_u32(tri_ranges, (-1, 2))), ptr(mm), c_u32(len(mm)), ptr(_f32(box, (6,))),
-                                  c_u32(max_leaf_tris), c_u32(max_depth), c_int(threads), _lib.ctypes.byref(h)))
+        build = L.rt_bsp_build if device is None else L.rt_bsp_build_device
+        _lib.check(build(ptr(_f32(inst_positions)), ptr(_u32(vertex_begin)), ptr(_u32(tris)),
+                         ptr(_u32(tri_ranges, (-1, 2))), ptr(mm), c_u32(len(mm)), ptr(_f32(box, (6,))),
+                         c_u32(max_leaf_tris), c_u32(max_depth), c_int(threads if device is None else device),
+                         _lib.ctypes.byref(h)))
         try:
             counts = np.zeros(5, np.uint32)
             L.rt_bsp_counts(h, ptr(counts))
@@ -273,8 +277,9 @@ class Scene:
         self.bounding_box = None
         self.bsp_tree = None
 
-    def preprocess(self, max_leaf_tris=32, max_depth=60, threads=0, device=None):
-        """`device`: run instancing and triangle preprocessing on that GPU instead of the host (same arrays)."""
+    def preprocess(self, max_leaf_tris=32, max_depth=60, threads=0, device=None, bsp_device=None):
+        """`device`: run instancing and triangle preprocessing on that GPU instead of the host (same arrays);
+        `bsp_device`: build the tree with rt_bsp_build_device on that GPU (same tree)."""
         self.preprocessed_materials = np.stack([preprocess_material(m) for m in self.materials])
         self.instantiated_meshes = instantiate_meshes(self.meshes.vertex_positions, self.meshes.vertex_normals,
                                                       self.meshes.vertex_ranges, self.models.mesh_transforms,
@@ -284,7 +289,7 @@ class Scene:
                                                  self.meshes.tri_ranges, self.models.meshes, device)
         self.bounding_box = scene_bounding_box(im.vertex_positions, self.inflate_mode)
         self.bsp_tree = BSPTree(im.vertex_positions, im.vertex_begin, self.meshes.tris, self.meshes.tri_ranges,
-                                self.models.meshes, self.bounding_box, max_leaf_tris, max_depth, threads)
+                                self.models.meshes, self.bounding_box, max_leaf_tris, max_depth, threads, bsp_device)
         return self
 
     def pixel_to_ray_transform(self, width, height):

@@ -748,6 +748,11 @@ def test_cpp_host_layer_program_matches_python_path(tmp_path):
     assert run.returncode == 0, run.stderr[-2000:]
     through = np.frombuffer(out3.read_bytes(), np.uint8, offset=len(header)).reshape(270, 480, 3)
     assert (through != theirs).any(-1).mean() < 0.01
+    # the tree built with the per-level work on the GPU: the same tree, so the same file
+    out4 = tmp_path / "gpu_build.ppm"
+    run = subprocess.run([exe, "480", "270", "4", "11", str(out4), "--gpu-build"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert out4.read_bytes() == out.read_bytes()
 
 
 @pytest.mark.parametrize("accel", ["bsp", "bvh"])
