@@ -102,6 +102,14 @@ int rt_bsp_build(const float* inst_positions, const uint32_t* model_vertex_begin
 int rt_bsp_build_device(const float* inst_positions, const uint32_t* model_vertex_begin, const uint32_t* base_tris,
                         const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,
                         const float root_box[6], uint32_t max_leaf_tris, uint32_t max_depth, int device, rt_bsp** out);
+/* For every box of boxes6 (min xyz, max xyz), the number of triangles of the WHOLE scene that pass the reference's
+ * triangle/box predicate (src/geometry.hpp:217-428) on it: what the reference's constructor computes at every node
+ * (src/bsp.hpp:188-211), evaluated on GPU `device` without any candidate list.  A check on the builders for scenes far
+ * beyond the reference's own reach: a leaf's box must give the leaf's size, an empty child's box 0, a divided node's
+ * box more than max_leaf_tris. */
+int rt_bsp_exhaustive_counts_device(const float* inst_positions, const uint32_t* model_vertex_begin, const uint32_t* base_tris,
+                                    const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,
+                                    const float* boxes6, uint32_t box_count, int device, uint32_t* counts);
 void rt_bsp_destroy(rt_bsp* bsp);
 /* Sizes: inode_count, leaf_count, ref_count, depth, oversized_leaves. */
 void rt_bsp_counts(const rt_bsp* bsp, uint32_t counts[5]);

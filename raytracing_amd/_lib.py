@@ -80,7 +80,7 @@ DEVICE_SYMBOLS = ["rt_scene_create", "rt_scene_serialize", "rt_scene_desc_from_b
                   "rt_last_error", "rt_abi_version"]
 HOST_SYMBOLS = ["rt_preprocess_material", "rt_quat_from_euler", "rt_camera_basis", "rt_pixel_to_ray_transform",
                 "rt_instantiate_meshes", "rt_preprocess_tris", "rt_instantiate_meshes_device", "rt_preprocess_tris_device", "rt_scene_bounding_box", "rt_line_intersects_box",
-                "rt_tri_intersects_box", "rt_srgb_to_linear", "rt_linear_to_srgb", "rt_bsp_build", "rt_bsp_build_device", "rt_bsp_destroy", "rt_bsp_counts", "rt_bsp_view", "rt_bvh4_build", "rt_bvh4_destroy", "rt_bvh4_counts", "rt_bvh4_view", "rt_write_ppm",
+                "rt_tri_intersects_box", "rt_srgb_to_linear", "rt_linear_to_srgb", "rt_bsp_build", "rt_bsp_build_device", "rt_bsp_exhaustive_counts_device", "rt_bsp_destroy", "rt_bsp_counts", "rt_bsp_view", "rt_bvh4_build", "rt_bvh4_destroy", "rt_bvh4_counts", "rt_bvh4_view", "rt_write_ppm",
                 "rt_mesh_load", "rt_mesh_counts", "rt_mesh_view", "rt_mesh_destroy", "rt_mesh_last_error"]
 
 _lib = None

@@ -165,6 +165,32 @@ __global__ void k_level_scatter(const uint32_t* __restrict__ cand, const uint32_
     }
 }
 
+// One lane per box: how many triangles of the whole scene pass the exact predicate on it.  Triangles go through LDS a
+// tile at a time, every lane of the block tests the same triangle against its own box.
+__global__ __launch_bounds__(256) void k_exhaustive_counts(const float* __restrict__ tri9, uint32_t tris,
+                                                           const float* __restrict__ boxes6, uint32_t boxes,
+                                                           uint32_t* __restrict__ counts) {
+    __shared__ float tile[256 * 9];
+    uint32_t const b = blockIdx.x * blockDim.x + threadIdx.x;
+    float box[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (b < boxes)
+        for (int k = 0; k < 6; ++k) box[k] = boxes6[6 * static_cast<size_t>(b) + k];
+    uint32_t count = 0;
+    for (uint32_t first = 0; first < tris; first += 256u) {
+        uint32_t const n = min(256u, tris - first);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < 9u * n; k += 256u) tile[k] = tri9[9 * static_cast<size_t>(first) + k];
+        __syncthreads();
+        if (b < boxes)
+            for (uint32_t j = 0; j < n; ++j) {
+                const float* t = tile + 9 * j;
+                V3 const a = {t[0], t[1], t[2]}, bb = {t[3], t[4], t[5]}, c = {t[6], t[7], t[8]};
+                count += triBoxDevice(a, bb, c, box) ? 1u : 0u;
+            }
+    }
+    if (b < boxes) counts[b] = count;
+}
+
 struct LevelNode {
     float box[6];
     uint8_t axis;
@@ -388,7 +414,57 @@ int buildOnDevice(const float* inst_positions, const uint32_t* model_vertex_begi
     return RT_OK;
 }
 
+// Flattens the scene's triangles (9 floats each, model after model) as both builders do.
+void flattenTriangles(const float* inst_positions, const uint32_t* model_vertex_begin, const uint32_t* base_tris,
+                      const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,
+                      std::vector<float>& tri9) {
+    size_t total = 0;
+    for (uint32_t m = 0; m < model_count; ++m) total += mesh_tri_ranges[2 * model_meshes[m] + 1];
+    tri9.resize(9 * total);
+    size_t g = 0;
+    for (uint32_t m = 0; m < model_count; ++m) {
+        uint32_t const begin = mesh_tri_ranges[2 * model_meshes[m]], count = mesh_tri_ranges[2 * model_meshes[m] + 1];
+        const float* verts = inst_positions + 3 * static_cast<size_t>(model_vertex_begin[m]);
+        for (uint32_t k = 0; k < count; ++k, ++g) {
+            const uint32_t* idx = base_tris + 3 * static_cast<size_t>(begin + k);
+            for (int v = 0; v < 3; ++v) std::memcpy(tri9.data() + 9 * g + 3 * v, verts + 3 * static_cast<size_t>(idx[v]), 12);
+        }
+    }
+}
+
+int exhaustiveCounts(const std::vector<float>& tri9, const float* boxes6, uint32_t box_count, int device, uint32_t* counts) {
+    if (tri9.size() / 9 >= (1ull << 32)) return rt_internal_fail(RT_ERR_LIMIT, "rt_bsp_exhaustive_counts_device: more than 2^32 triangles");
+    BSPG_TRY(hipSetDevice(device));
+    DevArray dTri, dBoxes, dCounts;
+    BSPG_TRY(dTri.reserve(tri9.size() * 4));
+    BSPG_TRY(dBoxes.reserve(static_cast<size_t>(box_count) * 24));
+    BSPG_TRY(dCounts.reserve(static_cast<size_t>(box_count) * 4));
+    if (!tri9.empty()) BSPG_TRY(hipMemcpy(dTri.p, tri9.data(), tri9.size() * 4, hipMemcpyHostToDevice));
+    BSPG_TRY(hipMemcpy(dBoxes.p, boxes6, static_cast<size_t>(box_count) * 24, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_exhaustive_counts, dim3((box_count + 255) / 256), dim3(256), 0, nullptr, dTri.as<float>(),
+                       static_cast<uint32_t>(tri9.size() / 9), dBoxes.as<float>(), box_count, dCounts.as<uint32_t>());
+    BSPG_TRY(hipGetLastError());
+    BSPG_TRY(hipMemcpy(counts, dCounts.p, static_cast<size_t>(box_count) * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 }  // namespace
+
+extern "C" int rt_bsp_exhaustive_counts_device(const float* inst_positions, const uint32_t* model_vertex_begin,
+                                               const uint32_t* base_tris, const uint32_t* mesh_tri_ranges,
+                                               const uint32_t* model_meshes, uint32_t model_count, const float* boxes6,
+                                               uint32_t box_count, int device, uint32_t* counts) {
+    if (!inst_positions || !model_vertex_begin || !base_tris || !mesh_tri_ranges || !model_meshes || (box_count && (!boxes6 || !counts)))
+        return rt_internal_fail(RT_ERR_INVALID, "rt_bsp_exhaustive_counts_device: null argument");
+    if (box_count == 0) return RT_OK;
+    try {
+        std::vector<float> tri9;
+        flattenTriangles(inst_positions, model_vertex_begin, base_tris, mesh_tri_ranges, model_meshes, model_count, tri9);
+        return exhaustiveCounts(tri9, boxes6, box_count, device, counts);
+    }
+    catch (std::bad_alloc const&) { return rt_internal_fail(RT_ERR_NOMEM, "rt_bsp_exhaustive_counts_device: out of host memory"); }
+    catch (...) { return rt_internal_fail(RT_ERR_INVALID, "rt_bsp_exhaustive_counts_device: unexpected exception"); }
+}
 
 extern "C" int rt_bsp_build_device(const float* inst_positions, const uint32_t* model_vertex_begin, const uint32_t* base_tris,
                                    const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,

@@ -265,6 +265,19 @@ class BSPTree:
             L.rt_bsp_destroy(h)
 
 
+def exhaustive_box_counts(inst_positions, vertex_begin, tris, tri_ranges, instance_meshes, boxes, device=0):
+    """Per box, how many triangles of the whole scene pass the reference's triangle/box predicate
+    (src/geometry.hpp:217-428), evaluated on a GPU with no candidate list: the numbers the reference's constructor
+    computes at every node (src/bsp.hpp:188-211)."""
+    b = _f32(boxes, (-1, 6))
+    mm = _u32(instance_meshes)
+    counts = np.zeros(len(b), np.uint32)
+    _lib.check(_lib.lib().rt_bsp_exhaustive_counts_device(
+        ptr(_f32(inst_positions)), ptr(_u32(vertex_begin)), ptr(_u32(tris)), ptr(_u32(tri_ranges, (-1, 2))), ptr(mm),
+        c_u32(len(mm)), ptr(b), c_u32(len(b)), c_int(device), ptr(counts)))
+    return counts
+
+
 class Scene:
     """src/scene.hpp:29-41 plus the preprocessing sequence of src/main.cpp:191-216."""
 

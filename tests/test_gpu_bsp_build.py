@@ -75,3 +75,41 @@ def test_device_build_of_an_empty_scene_and_bad_arguments():
     L = _lib.lib()
     assert L.rt_bsp_build_device(None, None, None, None, None, 0, None, 32, 60, 0, None) == -1
     assert b"rt_bsp_build_device" in L.rt_last_error()
+
+
+def _check_tree_against_every_triangle(sc, max_leaf_tris=32, sample=None):
+    """The reference's constructor tests every triangle of the scene against every node box (src/bsp.hpp:188-211) and
+    divides a node on its 33rd triangle.  The same numbers, computed on the GPU with no candidate list, must describe
+    the builder's tree: a leaf's box holds exactly the leaf's triangles, an empty child's box none, a divided node's
+    box more than 32.  (The builder's lists are subsets of the true ones by construction, so equal counts mean equal
+    lists.)"""
+    t = sc.bsp_tree
+    im = sc.instantiated_meshes
+    boxes = np.concatenate([t.root_box[None], t.inodes["neg_box"], t.inodes["pos_box"]])
+    index = np.concatenate([[t.root_index], t.inodes["neg_index"], t.inodes["pos_index"]]).astype(np.int64)
+    if sample is not None and sample < len(boxes):          # a random subset of the node boxes
+        pick = np.sort(np.random.default_rng(17).choice(len(boxes), sample, replace=False))
+        boxes, index = boxes[pick], index[pick]
+    t0 = time.perf_counter()
+    counts = S.exhaustive_box_counts(im.vertex_positions, im.vertex_begin, sc.meshes.tris, sc.meshes.tri_ranges,
+                                     sc.models.meshes, boxes).astype(np.int64)
+    dt = time.perf_counter() - t0
+    sizes = np.diff(t.leaf_first_ref.astype(np.int64))
+    leaf = index < 0
+    assert np.array_equal(counts[leaf], sizes[-index[leaf] - 1])
+    assert (counts[index == 0] == 0).all()
+    assert (counts[index > 0] > max_leaf_tris).all()
+    return len(boxes), dt
+
+
+def test_trees_hold_what_a_scan_of_every_triangle_finds():
+    n, _ = _check_tree_against_every_triangle(scenes.builtin_scene(3).preprocess())
+    assert n > 3
+    _check_tree_against_every_triangle(scenes.cornell_scene().preprocess())
+    sc = scenes.dragon_scale_scene(900_000).preprocess()
+    n, dt = _check_tree_against_every_triangle(sc)
+    print(f"0.9 M triangles against {n} node boxes ({n * len(sc.preprocessed_tris.tris) / 1e9:.0f} G predicate calls): {dt:.2f} s")
+    # the 9.9 M-triangle scene (eleven instances, tree built on the device): 40 000 of its 2.5 M node boxes
+    sc = scenes.multi_mesh_scene().preprocess(device=0, bsp_device=0)
+    n, dt = _check_tree_against_every_triangle(sc, sample=40_000)
+    print(f"9.9 M triangles against {n} sampled node boxes: {dt:.2f} s")
