@@ -441,9 +441,15 @@ int exhaustiveCounts(const std::vector<float>& tri9, const float* boxes6, uint32
     BSPG_TRY(dCounts.reserve(static_cast<size_t>(box_count) * 4));
     if (!tri9.empty()) BSPG_TRY(hipMemcpy(dTri.p, tri9.data(), tri9.size() * 4, hipMemcpyHostToDevice));
     BSPG_TRY(hipMemcpy(dBoxes.p, boxes6, static_cast<size_t>(box_count) * 24, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_exhaustive_counts, dim3((box_count + 255) / 256), dim3(256), 0, nullptr, dTri.as<float>(),
-                       static_cast<uint32_t>(tri9.size() / 9), dBoxes.as<float>(), box_count, dCounts.as<uint32_t>());
-    BSPG_TRY(hipGetLastError());
+    // in launches of 262 144 boxes (four blocks per CU), so that no single launch runs for minutes on a large scene
+    for (uint32_t first = 0; first < box_count; first += 262144u) {
+        uint32_t const n = std::min(262144u, box_count - first);
+        hipLaunchKernelGGL(k_exhaustive_counts, dim3((n + 255) / 256), dim3(256), 0, nullptr, dTri.as<float>(),
+                           static_cast<uint32_t>(tri9.size() / 9), dBoxes.as<float>() + 6 * static_cast<size_t>(first), n,
+                           dCounts.as<uint32_t>() + first);
+        BSPG_TRY(hipGetLastError());
+        BSPG_TRY(hipDeviceSynchronize());
+    }
     BSPG_TRY(hipMemcpy(counts, dCounts.p, static_cast<size_t>(box_count) * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
