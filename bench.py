@@ -199,6 +199,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU when weak, per frame when strong)")
     ap.add_argument("--roulette", action="store_true", help="render with RT_FLAG_RUSSIAN_ROULETTE")
     ap.add_argument("--lobes", action="store_true", help="render with RT_FLAG_LOBE_SAMPLING (per-lobe sampling)")
+    ap.add_argument("--sort", action="store_true", help="render with RT_FLAG_SORT_RAYS (live paths re-ordered per bounce)")
     ap.add_argument("--accel", default="bsp", choices=["bsp", "bvh"],
                     help="bsp: the reference's tree (results bit-identical to the reference's traversal); bvh: the "
                          "alternative accelerator, a 4-wide bounding volume hierarchy (RT_FLAG_ACCEL_BVH)")
@@ -279,7 +280,7 @@ def main():
     gatherer = tiles.FrameGatherer(width, height, rank, world, bands_per_rank, dist,
                                    buffer=(torch.zeros(render_buf.numel()) if share_gpu and world > 1 else render_buf))
     extra = ((_lib.RT_FLAG_RUSSIAN_ROULETTE if args.roulette else 0) | (_lib.RT_FLAG_ACCEL_BVH if args.accel == "bvh" else 0)
-             | (_lib.RT_FLAG_LOBE_SAMPLING if args.lobes else 0))
+             | (_lib.RT_FLAG_LOBE_SAMPLING if args.lobes else 0) | (_lib.RT_FLAG_SORT_RAYS if args.sort else 0))
 
     def step(seed, flags, spp_step):
         def render_rows(y0, rows, row_group, row_stride, out):
@@ -332,7 +333,7 @@ def main():
             "dtype": "f32", "data": "synthetic (procedural scene, random-free geometry; counter-based sampler)",
             "config": {"workload": description, "name": args.workload, "width": width, "height": height,
                        "spp_total": spp, "spp_per_gpu": spp1, "bounce_limit": bounce_limit,
-                       "russian_roulette": bool(args.roulette), "per_lobe_sampling": bool(args.lobes), "triangles": triangles, "tree_depth": ds.depth,
+                       "russian_roulette": bool(args.roulette), "per_lobe_sampling": bool(args.lobes), "sorted_rays": bool(args.sort), "triangles": triangles, "tree_depth": ds.depth,
                        "accelerator": "reference BSP tree" if args.accel == "bsp" else "4-wide bounding volume hierarchy (not the reference's accelerator)",
                        "bvh_build_s": bvh_build_s,
                        "parallelism": (f"pixel bands over {world} GPUs, scene broadcast once from rank 0 "

@@ -130,6 +130,13 @@ typedef struct {
  * diffuse part), weighted by BRDF * cos / (pS pdfS + (1 - pS) pdfD).  Same expectation, less variance on glossy
  * dielectrics.  The lobe is chosen with the fourth word of the bounce's Philox block. */
 #define RT_FLAG_LOBE_SAMPLING 16u
+/* Before every bounce but the first, sort the queue of live paths by the cell of the ray's origin (32 x 32 x 32 grid
+ * over the root box, Morton order) and the octant of its direction, so that the lanes of a wave start in the same part
+ * of the tree.  Only the order in which paths are traced changes: the image is the same bit for bit.  Costs one
+ * stream synchronisation per bounce and 8 more bytes of workspace per path; off by default because on the scenes
+ * measured the sort costs more than the traversal gains.  Not available in rt_render_device_static.  No counterpart
+ * in the reference. */
+#define RT_FLAG_SORT_RAYS 32u
 /* For the front_only argument of rt_intersect / rt_intersect_device: bit 0 = front faces only
  * (Surfaces::FRONT_ONLY, src/geometry.hpp:95-97), bit 1 = use the attached bounding volume hierarchy. */
 #define RT_INTERSECT_FRONT_ONLY 1

@@ -212,6 +212,7 @@ struct RenderOptions {                                     // src/render.hpp:47-
     bool russianRoulette = false;          // RT_FLAG_RUSSIAN_ROULETTE
     bool perLobeSampling = false;          // RT_FLAG_LOBE_SAMPLING
     bool boundingVolumeHierarchy = false;  // RT_FLAG_ACCEL_BVH: the alternative accelerator instead of the BSP tree
+    bool sortRays = false;                 // RT_FLAG_SORT_RAYS: live paths re-ordered by origin cell and octant per bounce
 };
 
 // A scene resident on one GPU: RayTraceData uploaded once, rendered many times.
@@ -271,7 +272,7 @@ inline rt_render_params renderParams(RenderData const& data, RenderOptions const
     p.camera_position[0] = data.cameraPosition.x; p.camera_position[1] = data.cameraPosition.y; p.camera_position[2] = data.cameraPosition.z;
     for (int i = 0; i < 9; ++i) p.pixel_to_ray[i] = data.pixelToRayTransform[i];
     p.flags = (o.russianRoulette ? RT_FLAG_RUSSIAN_ROULETTE : 0u) | (o.perLobeSampling ? RT_FLAG_LOBE_SAMPLING : 0u)
-              | (o.boundingVolumeHierarchy ? RT_FLAG_ACCEL_BVH : 0u);
+              | (o.boundingVolumeHierarchy ? RT_FLAG_ACCEL_BVH : 0u) | (o.sortRays ? RT_FLAG_SORT_RAYS : 0u);
     return p;
 }
 

@@ -70,6 +70,7 @@ RT_FLAG_PROFILE_KERNELS = 2
 RT_FLAG_RUSSIAN_ROULETTE = 4
 RT_FLAG_ACCEL_BVH = 8
 RT_FLAG_LOBE_SAMPLING = 16
+RT_FLAG_SORT_RAYS = 32
 RT_INTERSECT_FRONT_ONLY = 1
 RT_INTERSECT_BVH = 2
 RT_STATIC_MAX_PIXELS = 262144

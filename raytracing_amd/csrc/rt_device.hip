@@ -1462,6 +1462,12 @@ __global__ void k_selftest(int op, const float* __restrict__ a, const float* __r
 // Host side of the C ABI
 // ------------------------------------------------------------------------------------------------
 
+// rt_sort.hip
+int rt_internal_sort_temp_bytes(uint32_t maxN, size_t* bytes);
+int rt_internal_sort_rays(const void* A, const void* B, uint32_t* queue, uint32_t* alt, uint32_t* keys0, uint32_t* keys1,
+                          void* temp, size_t tempBytes, uint32_t n, const float rootLo[3], const float rootHi[3],
+                          hipStream_t stream);
+
 // Path-state buffers of one render call.  Two sets exist: the scene's own, allocated with hipMalloc and
 // grown on demand (rt_render_device), and a fixed-size one carved out of the file-scope `scratch`
 // array (rt_render_device_static), which never allocates.
@@ -1473,6 +1479,11 @@ struct Workspace {
     Counters* counters = nullptr;
     float* accum = nullptr;
     uint64_t paths = 0, pixels = 0;     // capacity
+    // RT_FLAG_SORT_RAYS only (allocated on first use): two key arrays and the radix sort's temporary storage
+    uint32_t *sortKeys0 = nullptr, *sortKeys1 = nullptr;
+    void* sortTemp = nullptr;
+    size_t sortTempBytes = 0;
+    uint64_t sortPaths = 0;
 };
 
 struct rt_scene {
@@ -1563,8 +1574,13 @@ int bindStaticWorkspace(rt_scene* s) {
 void freeWorkspace(rt_scene* s) {
     Workspace& W = s->ws;
     for (void* p : {static_cast<void*>(W.A), static_cast<void*>(W.B), static_cast<void*>(W.L), static_cast<void*>(W.hit), static_cast<void*>(W.Tz),
-                    static_cast<void*>(W.q0), static_cast<void*>(W.q1), static_cast<void*>(W.accum)})
+                    static_cast<void*>(W.q0), static_cast<void*>(W.q1), static_cast<void*>(W.accum), static_cast<void*>(W.sortKeys0),
+                    static_cast<void*>(W.sortKeys1), W.sortTemp})
         if (p) (void)hipFree(p);
+    W.sortKeys0 = W.sortKeys1 = nullptr;
+    W.sortTemp = nullptr;
+    W.sortTempBytes = 0;
+    W.sortPaths = 0;
     W.A = W.B = W.L = W.hit = nullptr;
     W.Tz = nullptr;
     W.q0 = W.q1 = nullptr;
@@ -2051,6 +2067,8 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
     R.rowSkip = interleaved ? p->row_group * (p->row_stride - 1u) : 0u;
 
     bool const countWork = (p->flags & RT_FLAG_COUNT_WORK) != 0;
+    bool const sortRays = (p->flags & RT_FLAG_SORT_RAYS) != 0;
+    if (sortRays && !W.sortKeys0) return fail(RT_ERR_INVALID, "rt_render: RT_FLAG_SORT_RAYS needs buffers this entry point does not have");
     size_t eventsUsed = 0;
     std::vector<int8_t> evKind;           // kind of the interval an event opens, -1 for a closing event
     auto mark = [&](int kind) {
@@ -2110,6 +2128,15 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
             mark(-1);
             mark(2);
             hipLaunchKernelGGL(k_shade, dim3(gridFor(s, paths, s->shadeBlocksPerCu)), dim3(RT_BLOCK), 0, st, dev, R, P, b, done, M, gc);
+            if (sortRays && b + 1 < bounceCount) {
+                // the next bounce's queue, re-ordered by origin cell and direction octant (timed with the shading)
+                uint32_t live = 0;
+                HIP_TRY(hipMemcpyAsync(&live, P.counts + b + 1, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                int const rcSort = rt_internal_sort_rays(P.A, P.B, P.queue[(b + 1) & 1], P.queue[b & 1], W.sortKeys0, W.sortKeys1,
+                                                         W.sortTemp, W.sortTempBytes, live, s->dev.rootLo, s->dev.rootHi, st);
+                if (rcSort != RT_OK) return rcSort;
+            }
             mark(-1);
             ++traceLaunches;
         }
@@ -2346,6 +2373,24 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
                 return fail(RT_ERR_HIP, std::string("rt_render: workspace allocation failed: ") + hipGetErrorString(e));
             maxPaths = std::max<uint64_t>(pixels, batchPaths / 2);
         }
+        if ((p->flags & RT_FLAG_SORT_RAYS) && W.sortPaths < W.paths) {
+            HIP_TRY(hipStreamSynchronize(st));
+            for (void* q : {static_cast<void*>(W.sortKeys0), static_cast<void*>(W.sortKeys1), W.sortTemp}) if (q) (void)hipFree(q);
+            W.sortKeys0 = W.sortKeys1 = nullptr; W.sortTemp = nullptr; W.sortPaths = 0;
+            int const rcT = rt_internal_sort_temp_bytes(static_cast<uint32_t>(W.paths), &W.sortTempBytes);
+            if (rcT != RT_OK) return rcT;
+            void* ptr = nullptr;
+            hipError_t e = hipMalloc(&ptr, W.paths * 4); W.sortKeys0 = static_cast<uint32_t*>(ptr); ptr = nullptr;
+            if (e == hipSuccess) { e = hipMalloc(&ptr, W.paths * 4); W.sortKeys1 = static_cast<uint32_t*>(ptr); ptr = nullptr; }
+            if (e == hipSuccess) e = hipMalloc(&W.sortTemp, std::max<size_t>(W.sortTempBytes, 256));
+            if (e != hipSuccess) {
+                for (void* q : {static_cast<void*>(W.sortKeys0), static_cast<void*>(W.sortKeys1), W.sortTemp}) if (q) (void)hipFree(q);
+                W.sortKeys0 = W.sortKeys1 = nullptr; W.sortTemp = nullptr;
+                (void)hipGetLastError();
+                return fail(RT_ERR_HIP, std::string("rt_render: allocation of the ray sort's buffers failed: ") + hipGetErrorString(e));
+            }
+            W.sortPaths = W.paths;
+        }
         return renderCore(s, p, d_out, stats, st, W, spb, (p->flags & RT_FLAG_PROFILE_KERNELS) != 0);
     });
 }
@@ -2358,6 +2403,8 @@ int rt_render_device_static(rt_scene* s, const rt_render_params* p, float* d_out
         return fail(RT_ERR_LIMIT, "rt_render_device_static: rectangle larger than 262144 pixels (RT_STATIC_MAX_PIXELS)");
     if (p->flags & RT_FLAG_PROFILE_KERNELS)
         return fail(RT_ERR_INVALID, "rt_render_device_static: RT_FLAG_PROFILE_KERNELS creates events and is not available here");
+    if (p->flags & RT_FLAG_SORT_RAYS)
+        return fail(RT_ERR_INVALID, "rt_render_device_static: RT_FLAG_SORT_RAYS needs buffers outside the static workspace and is not available here");
     if (!s->wsStatic.A) return fail(RT_ERR_LIMIT, "rt_render_device_static: no static workspace on this device index");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t const st = static_cast<hipStream_t>(hip_stream);

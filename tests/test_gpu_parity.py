@@ -656,6 +656,36 @@ def test_per_lobe_sampling_bit_exact_unbiased_and_less_noisy(builtin, oracle_lib
         assert abs(img[..., c].mean() / ref[..., c].mean() - 1.0) < 0.01
 
 
+@pytest.mark.parametrize("name,extra", [("builtin", 0), ("displaced", 0), ("cornell", _lib.RT_FLAG_RUSSIAN_ROULETTE),
+                                        ("displaced", _lib.RT_FLAG_ACCEL_BVH)])
+def test_sorted_ray_queues_change_nothing_but_the_order(name, extra):
+    """RT_FLAG_SORT_RAYS re-orders the queue of live paths before every bounce: same image bit for bit, same work."""
+    sc = {"builtin": lambda: scenes.builtin_scene(3), "cornell": scenes.cornell_scene,
+          "displaced": lambda: scenes.dragon_scale_scene(60_000)}[name]().preprocess()
+    ds = DeviceScene(RayTraceData(sc))
+    try:
+        if extra & _lib.RT_FLAG_ACCEL_BVH:
+            ds.build_bvh(4)
+        w, h = 384, 216
+        base = _lib.RT_FLAG_COUNT_WORK | extra
+        p0 = ds.make_params(w, h, sc.camera.position, sc.pixel_to_ray_transform(w, h), spp=6, seed=21, flags=base)
+        p1 = ds.make_params(w, h, sc.camera.position, sc.pixel_to_ray_transform(w, h), spp=6, seed=21,
+                            flags=base | _lib.RT_FLAG_SORT_RAYS)
+        img0, st0 = ds.render(p0)
+        img1, st1 = ds.render(p1)
+        assert same_bits(img0, img1)
+        for k in ("segments", "paths", "shaded_hits", "box_tests", "tris_tested", "leaf_visits", "inode_visits"):
+            assert st0[k] == st1[k], k
+        assert st1["box_filter_errors"] == 0
+        # several batches, and a plain (non-counting) render
+        p2 = ds.make_params(w, h, sc.camera.position, sc.pixel_to_ray_transform(w, h), spp=6, seed=21,
+                            flags=extra | _lib.RT_FLAG_SORT_RAYS, max_batch_paths=w * h * 2)
+        img2, st2 = ds.render(p2)
+        assert same_bits(img0, img2) and st2["batches"] == 3
+    finally:
+        ds.close()
+
+
 @pytest.mark.parametrize("name", ["builtin", "cornell", "displaced"])
 def test_box_filter_never_contradicts_exact_test(name):
     """The production kernels decide most ray/box pairs with a conservative slab filter and fall back to the

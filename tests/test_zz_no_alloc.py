@@ -61,5 +61,8 @@ def test_static_workspace_render_matches_allocating_render():
         prof = ds.make_params(w, h, sc.camera.position, p2r, spp=1, rect=(0, 0, 64, 64), flags=_lib.RT_FLAG_PROFILE_KERNELS)
         with pytest.raises(_lib.RtError, match="PROFILE"):
             ds.render_device_static(prof, out, stream=stream)
+        sort = ds.make_params(w, h, sc.camera.position, p2r, spp=1, rect=(0, 0, 64, 64), flags=_lib.RT_FLAG_SORT_RAYS)
+        with pytest.raises(_lib.RtError, match="SORT_RAYS"):
+            ds.render_device_static(sort, out, stream=stream)
     finally:
         ds.close()
