@@ -17,7 +17,10 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -242,6 +245,12 @@ struct Emitter {
 int buildOnDevice(const float* inst_positions, const uint32_t* model_vertex_begin, const uint32_t* base_tris,
                   const uint32_t* mesh_tri_ranges, const uint32_t* model_meshes, uint32_t model_count,
                   const float root_box[6], uint32_t maxLeaf, uint32_t maxDepth, int device, rt_bsp& bsp) {
+    auto const t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (std::getenv("RT_AMD_DEBUG"))
+            std::fprintf(stderr, "rt_amd: rt_bsp_build_device: %s at %.3f s\n", what,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
     // ---- triangles, flattened as in rt_bsp_build ------------------------------------------------------
     size_t total = 0;
     for (uint32_t m = 0; m < model_count; ++m) total += mesh_tri_ranges[2 * model_meshes[m] + 1];
@@ -269,6 +278,7 @@ int buildOnDevice(const float* inst_positions, const uint32_t* model_vertex_begi
         }
     }
     float const slack = 1e-4f * scale;          // as in rt_bsp_build
+    lap("triangles flattened");
 
     BSPG_TRY(hipSetDevice(device));
     DevArray dTri, dBounds, dNodeBox, dNodeAxis, dBegin, dDest, dCand[2], dPairNode[2], dIn, dNeg, dPos, dSIn, dSNeg, dSPos,
@@ -407,10 +417,20 @@ int buildOnDevice(const float* inst_positions, const uint32_t* model_vertex_begi
         cur = nxt;
     }
 
+    lap("levels built");
     std::memcpy(bsp.root_box, root_box, sizeof bsp.root_box);
+    size_t splitNodes = 0, leafNodes = 0, leafRefs = 0;
+    for (Level const& L : levels) {
+        leafRefs += L.leafTris.size();
+        for (LevelNode const& n : L.nodes) { splitNodes += n.kind == 2; leafNodes += n.kind == 1; }
+    }
+    bsp.inodes.reserve(splitNodes);
+    bsp.leaf_first.reserve(leafNodes + 1);
+    bsp.refs.reserve(leafRefs);
     bsp.leaf_first.push_back(0);
     Emitter e{levels, triMesh, triTri, bsp, maxLeaf};
     bsp.root_index = e.emit(0, 0);
+    lap("numbered depth-first");
     return RT_OK;
 }
 

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Build time of the BSP tree on the host (16 threads, 1 thread) and with the per-level work on the GPU
+(rt_bsp_build_device), for the 0.9 M- and 9.9 M-triangle scenes.  Run on the GPU box from the repository root."""
 import sys, time
 sys.path.insert(0, '.')
 from raytracing_amd import scene as S, scenes
