@@ -231,6 +231,32 @@ __device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
     return static_cast<int32_t>(aux) >= 0 && ad > 0.0f && lhs >= rhs && lhs < INFINITY && rhs >= 0x1p-100f;
 }
 
+// ---- leaf triangle bounds --------------------------------------------------------------------------------
+// A leaf's box is a cell of the spatial subdivision; its triangles usually fill a fraction of it (0.4-0.5 of the volume
+// on the benchmark scenes), and half of the leaves a line enters (and whose cone does not already exclude them) it
+// leaves without coming near a triangle.  The scene therefore keeps, per leaf, the bounds of the triangles AS THE TEST
+// SEES THEM (v1, v1 + v1ToV2, v1 + v1ToV3) clipped to the leaf's box and padded by 2^-18 of the largest box coordinate,
+// rounded outwards.  An accepted hit lies on a triangle (barycentric test) and in the leaf's box (src/bsp.hpp:82-87),
+// both up to roundings far smaller than the padding, so a line that misses these bounds has no accepted hit in the leaf
+// and the leaf need not be scanned: same result as scanning it.  The interval ends are widened by 2^-16 relative; a
+// NaN (0 * inf on an axis-parallel line) makes the comparison false, i.e. no skip.  Kernels that count work scan every
+// leaf and count an accepted hit in a leaf these bounds would have skipped as an error (rt_stats.box_filter_errors).
+//
+// The record of slot s sits at nodes[-(s + 1)] (32 bytes, {lo.xyz, hi.x} {hi.yz, -, -}): the bounds are stored in
+// front of the node array, mirrored, so that the kernel needs no second base address.  That matters: the traversal
+// kernel for deep trees sits at 80 scalar registers, and with two more its time on a 0.9 M-triangle scene goes from 32
+// to 42 ms whatever the extra registers are used for.
+__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 r) {
+    const float4* bp = nodes - 2 * (static_cast<size_t>(slot) + 1);
+    float4 const b0 = bp[0], b1 = bp[1];
+    float const ax = (b0.x - o.x) * r.x, bx = (b0.w - o.x) * r.x;
+    float const ay = (b0.y - o.y) * r.y, by = (b1.x - o.y) * r.y;
+    float const az = (b0.z - o.z) * r.z, bz = (b1.y - o.z) * r.z;
+    float const tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float const tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return tn - fabsf(tn) * 0x1p-16f > tf + fabsf(tf) * 0x1p-16f;
+}
+
 // Diagnostic build only (-DRT_DIAG, make diag): per-phase cycle and lane-occupancy tallies of traceStream.
 #ifdef RT_DIAG
 __device__ unsigned long long g_diag[16];
@@ -439,7 +465,25 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
         DIAG_ADD(1, t2 - t1);
         uint32_t leafFirst = 0, leafCount = 0;
         bool coneSkips = false;           // counting kernels: the cone says "skip", to be checked against every triangle
+        bool boundsSkip = false;          // counting kernels: the triangle bounds say "skip", to be checked against every accepted hit
         V3 lo = mk(0.0f, 0.0f, 0.0f), hi = lo;
+        if (!COUNT) {
+            // The leaf to scan is the oldest one noted whose triangles the line does not pass clear of
+            // (missesLeafBounds).  Tested here, by all lanes together, and not where a leaf is noted: inside the walking
+            // loop the test would be issued for the two or three lanes that stand on a leaf, on almost every iteration.
+            // Branch-free per lane (a lane without a leaf tests slot 0 and ignores the answer): every level of divergent
+            // control flow holds two scalar registers, which this kernel does not have to spare, see missesLeafBounds.
+            bool drop = missesLeafBounds(S.nodes, pend1 != NONE ? pend1 : 0u, o, r) && pend1 != NONE;
+            pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? NONE : pend3;
+            if (__ballot(drop) != 0ull) {
+                drop = missesLeafBounds(S.nodes, pend1 != NONE ? pend1 : 0u, o, r) && pend1 != NONE;
+                pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? NONE : pend3;
+                if (__ballot(drop) != 0ull) {
+                    drop = missesLeafBounds(S.nodes, pend1 != NONE ? pend1 : 0u, o, r) && pend1 != NONE;
+                    pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? NONE : pend3;
+                }
+            }
+        }
         if (pend1 != NONE) {
             float4 const q0 = S.nodes[2 * pend1];
             float4 const q1 = S.nodes[2 * pend1 + 1];
@@ -447,6 +491,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             leafFirst = static_cast<uint32_t>(-(__float_as_int(q1.z) + 1));
             leafCount = leafTriCount(__float_as_uint(q1.w));
             coneSkips = COUNT && FRONT_ONLY && coneAllBackFacing(__float_as_uint(q1.w), d);
+            boundsSkip = COUNT && missesLeafBounds(S.nodes, pend1, o, r);
             pend1 = pend2; pend2 = pend3; pend3 = NONE;
         }
 
@@ -517,7 +562,10 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                     V3 const p = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
                     bool const inBox = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z
                                     && p.z <= hi.z;
-                    if (inBox) { best.t = t; best.u = u; best.v = v; best.ref = leafFirst + j; has = true; }
+                    if (inBox) {
+                        best.t = t; best.u = u; best.v = v; best.ref = leafFirst + j; has = true;
+                        if (COUNT && boundsSkip) c.boxFilterErrors++;
+                    }
                 }
             }
         }
@@ -1827,6 +1875,48 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     if (std::getenv("RT_AMD_DEBUG"))
         std::fprintf(stderr, "rt_amd: %llu of %llu leaves carry a normal cone, mean threshold %.3f\n", leavesWithCone, leavesSeen,
                      leavesWithCone ? double(thresholdSum) / 31.0 / double(leavesWithCone) : 0.0);
+    // ---- leaf triangle bounds in front of the node records (see missesLeafBounds) -------------------------------
+    // packed[N + s] = node record of slot s, packed[N - 1 - s] = bounds of the leaf at slot s
+    std::vector<HNode> packed(2 * nodes.size(), HNode{});
+    {
+        size_t const N = nodes.size();
+        double absMax = 0.0;
+        for (int k = 0; k < 3; ++k) absMax = std::max(absMax, std::max(std::fabs(double(nodes[0].lo[k])), std::fabs(double(nodes[0].hi[k]))));
+        double const pad = std::ldexp(absMax, -18);
+        // RT_AMD_LEAF_BOUNDS=0 (measurements): every leaf gets unbounded bounds, which no line misses
+        bool const unbounded = std::getenv("RT_AMD_LEAF_BOUNDS") && std::atoi(std::getenv("RT_AMD_LEAF_BOUNDS")) == 0;
+        for (size_t slot = 0; slot < N; ++slot) {
+            HNode const& node = nodes[slot];
+            packed[N + slot] = node;
+            if (node.index >= 0) continue;
+            uint32_t const first = static_cast<uint32_t>(-(node.index + 1));
+            uint32_t const leafCount = (node.aux & 0x80000000u) ? (node.aux & 0x7FFFFFFFu) : (node.aux & 0xFFu);
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            bool finite = !unbounded;
+            for (uint32_t i = 0; i < leafCount; ++i) {
+                float const* rec = leafTris.data() + 12 * static_cast<size_t>(first + i);       // normal, v1, v1ToV3, v1ToV2
+                for (int k = 0; k < 3; ++k) {
+                    double const a = rec[3 + k], b = a + double(rec[6 + k]), c = a + double(rec[9 + k]);
+                    if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(c)) finite = false;
+                    lo[k] = std::min(lo[k], std::min(a, std::min(b, c)));
+                    hi[k] = std::max(hi[k], std::max(a, std::max(b, c)));
+                }
+            }
+            HNode& out = packed[N - 1 - slot];
+            for (int k = 0; k < 3; ++k) {
+                double l = -INFINITY, h = INFINITY;              // non-finite vertices: no bounds
+                if (finite) {
+                    l = std::max(lo[k], double(node.lo[k])) - pad;
+                    h = std::min(hi[k], double(node.hi[k])) + pad;
+                }
+                float lf = static_cast<float>(l), hf = static_cast<float>(h);
+                if (double(lf) > l) lf = std::nextafter(lf, -INFINITY);
+                if (double(hf) < h) hf = std::nextafter(hf, INFINITY);
+                out.lo[k] = lf;
+                out.hi[k] = hf;
+            }
+        }
+    }
     std::vector<float> triNormals;
     {
         int const rc = gatherTriNormals(D, "rt_scene_create", triNormals);
@@ -1861,7 +1951,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     if (D->model_count) std::memcpy(mats.data(), D->model_materials, 48 * static_cast<size_t>(D->model_count));
     void* dCounts = nullptr;
     void* dCounters = nullptr;
-    hipError_t e = upload(&s->dNodes, nodes.data(), nodes.size() * sizeof(HNode));
+    hipError_t e = upload(&s->dNodes, packed.data(), packed.size() * sizeof(HNode));
     if (e == hipSuccess) e = upload(&s->dLeafTris, leafTris.data(), leafTris.size() * 4);
     if (e == hipSuccess) e = upload(&s->dLeafIds, leafIds.data(), leafIds.size() * 4);
     if (e == hipSuccess) e = upload(&s->dTriNormals, shadeRecs.data(), shadeRecs.size() * 4);
@@ -1871,7 +1961,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     if (e == hipSuccess) e = hipMalloc(&dCounters, 1024);
     s->ws.counters = static_cast<Counters*>(dCounters);
     if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_scene_create: upload failed: ") + hipGetErrorString(e));
-    s->dev.nodes = static_cast<const float4*>(s->dNodes);
+    s->dev.nodes = static_cast<const float4*>(s->dNodes) + 2 * nodes.size();         // the leaf bounds lie in front of it
     s->dev.leafTris = static_cast<const float4*>(s->dLeafTris);
     s->dev.leafIds = static_cast<const uint4*>(s->dLeafIds);
     s->dev.shadeRecs = static_cast<const float4*>(s->dTriNormals);
