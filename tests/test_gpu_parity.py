@@ -687,6 +687,37 @@ def test_sorted_ray_queues_change_nothing_but_the_order(name, extra):
 
 
 @pytest.mark.parametrize("name", ["builtin", "cornell", "displaced"])
+def test_leaf_triangle_bounds_change_nothing(name, monkeypatch):
+    """A leaf whose triangles the line passes clear of is dropped before it is scanned.  With the bounds switched off
+    (the library's measurement variable, read when the scene is uploaded) hits and images are the same bit for bit."""
+    sc = {"builtin": lambda: scenes.builtin_scene(3), "cornell": scenes.cornell_scene,
+          "displaced": lambda: scenes.dragon_scale_scene(60_000)}[name]().preprocess()
+    rng = np.random.default_rng(41)
+    n = 20000
+    lo, hi = sc.bounding_box[:3], sc.bounding_box[3:]
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    w, h = 320, 180
+    results = []
+    for switch in ("1", "0"):
+        monkeypatch.setenv("RT_AMD_LEAF_BOUNDS", switch)
+        ds = DeviceScene(RayTraceData(sc))
+        try:
+            hits = [ds.intersect(o, d, 1e-3, front).copy() for front in (True, False)]
+            p = ds.make_params(w, h, sc.camera.position, sc.pixel_to_ray_transform(w, h), spp=4, seed=9)
+            img, st = ds.render(p)
+            results.append((hits, img, st["segments"]))
+        finally:
+            ds.close()
+    (h1, i1, s1), (h0, i0, s0) = results
+    assert s1 == s0 and same_bits(i1, i0)
+    for a, b in zip(h1, h0):
+        assert a.tobytes() == b.tobytes()
+    assert (h1[0]["mesh"] != 0xFFFFFFFF).mean() > 0.2
+
+
+@pytest.mark.parametrize("name", ["builtin", "cornell", "displaced"])
 def test_box_filter_never_contradicts_exact_test(name):
     """The production kernels decide most ray/box pairs with a conservative slab filter and fall back to the
     reference's six-face test (src/geometry.hpp:135-214) otherwise.  The counting kernels run both on every
