@@ -242,11 +242,14 @@ __device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
 // NaN (0 * inf on an axis-parallel line) makes the comparison false, i.e. no skip.  Kernels that count work scan every
 // leaf and count an accepted hit in a leaf these bounds would have skipped as an error (rt_stats.box_filter_errors).
 //
-// The record of slot s sits at nodes[-(s + 1)] (32 bytes, {lo.xyz, hi.x} {hi.yz, -, -}): the bounds are stored in
+// The record of slot s sits at nodes[-(s + 1)] (32 bytes, {lo.xyz, hi.x} {hi.yz, cone word, -}): the bounds are stored in
 // front of the node array, mirrored, so that the kernel needs no second base address.  That matters: the traversal
 // kernel for deep trees sits at 80 scalar registers, and with two more its time on a 0.9 M-triangle scene goes from 32
 // to 42 ms whatever the extra registers are used for.
-__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 r) {
+// WITH_CONE: the leaf's normal cone (coneAllBackFacing; a copy of the leaf's cone word sits in the third word of the
+// record's second half) is tested in the same breath.
+template <bool WITH_CONE>
+__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r) {
     const float4* bp = nodes - 2 * (static_cast<size_t>(slot) + 1);
     float4 const b0 = bp[0], b1 = bp[1];
     float const ax = (b0.x - o.x) * r.x, bx = (b0.w - o.x) * r.x;
@@ -254,7 +257,9 @@ __device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ node
     float const az = (b0.z - o.z) * r.z, bz = (b1.y - o.z) * r.z;
     float const tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float const tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    return tn - fabsf(tn) * 0x1p-16f > tf + fabsf(tf) * 0x1p-16f;
+    bool miss = tn - fabsf(tn) * 0x1p-16f > tf + fabsf(tf) * 0x1p-16f;
+    if (WITH_CONE) miss = miss || coneAllBackFacing(__float_as_uint(b1.z), d);
+    return miss;
 }
 
 // Diagnostic build only (-DRT_DIAG, make diag): per-phase cycle and lane-occupancy tallies of traceStream.
@@ -330,7 +335,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     // per-lane line state
     bool active = false;
     uint32_t line = 0, cur = NONE;
-    uint32_t pend1 = NONE, pend2 = NONE, pend3 = NONE;     // leaves (node records) found and not yet scanned, oldest first
+    uint32_t pend1 = NONE, pend2 = NONE, pend3 = NONE, pend4 = NONE;     // leaves (node records) found and not yet scanned, oldest first
     int sp = 0;
     V3 o = mk(0.0f, 0.0f, 0.0f), d = o, r = o;
     float mu = INFINITY;
@@ -367,7 +372,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 mu = filterMargin(o, d, r, S.boxAbsMax);
                 sp = 0; cur = 0;
-                pend1 = NONE; pend2 = NONE; pend3 = NONE;
+                pend1 = NONE; pend2 = NONE; pend3 = NONE; pend4 = NONE;
                 best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
                 active = true;
             }
@@ -382,11 +387,11 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
 
         // ---- phase 1: interior nodes until a leaf is reached or nothing is left ------------------
         // A lane that has found its leaf would idle until the slowest lane of the wave has found one
-        // too; instead it keeps walking and notes the next leaves its line meets (at most two ahead).
+        // too; instead it keeps walking and notes the next leaves its line meets (at most three ahead).
         // If the first leaf yields a hit that work is discarded, otherwise it is already done; the
         // sequence of leaves scanned is unchanged.  Kernels that count work do not look ahead, so
         // that they count exactly the visits of the reference.
-        while (cur != NONE && pend3 == NONE) {
+        while (cur != NONE && pend4 == NONE) {
             if (!COUNT) { if (__ballot(pend1 == NONE) == 0ull) break; }
             DIAG_LANES(6, 7);
             DIAG_WAVE(5);
@@ -454,8 +459,12 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             else cur = NONE;
             if (meets && index < 0) {
                 // a leaf whose triangles all face away from the origin needs no scan (coneAllBackFacing)
-                if (COUNT || !FRONT_ONLY || !coneAllBackFacing(aux, d)) {
-                    if (pend1 == NONE) pend1 = here; else if (pend2 == NONE) pend2 = here; else pend3 = here;
+                // (kernels for deep trees test the cone later, together with the leaf's triangle bounds: there the test
+                // costs more as part of every walking step than the leaves it keeps out of the list are worth, 26.6 ->
+                // 24.6 ms on a 0.9 M-triangle scene; on a 4 k-triangle scene, whose waves are coherent, it is the other
+                // way round, 33.0 against 34.8 ms)
+                if (COUNT || !FRONT_ONLY || SPILL || !coneAllBackFacing(aux, d)) {
+                    if (pend1 == NONE) pend1 = here; else if (pend2 == NONE) pend2 = here; else if (pend3 == NONE) pend3 = here; else pend4 = here;
                 }
                 if (COUNT) break;
             }
@@ -473,14 +482,18 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             // loop the test would be issued for the two or three lanes that stand on a leaf, on almost every iteration.
             // Branch-free per lane (a lane without a leaf tests slot 0 and ignores the answer): every level of divergent
             // control flow holds two scalar registers, which this kernel does not have to spare, see missesLeafBounds.
-            bool drop = missesLeafBounds(S.nodes, pend1 != NONE ? pend1 : 0u, o, r) && pend1 != NONE;
-            pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? NONE : pend3;
+            bool drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r) && pend1 != NONE;
+            pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
             if (__ballot(drop) != 0ull) {
-                drop = missesLeafBounds(S.nodes, pend1 != NONE ? pend1 : 0u, o, r) && pend1 != NONE;
-                pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? NONE : pend3;
+                drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r) && pend1 != NONE;
+                pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                 if (__ballot(drop) != 0ull) {
-                    drop = missesLeafBounds(S.nodes, pend1 != NONE ? pend1 : 0u, o, r) && pend1 != NONE;
-                    pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? NONE : pend3;
+                    drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r) && pend1 != NONE;
+                    pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
+                    if (__ballot(drop) != 0ull) {
+                        drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r) && pend1 != NONE;
+                        pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
+                    }
                 }
             }
         }
@@ -491,8 +504,8 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             leafFirst = static_cast<uint32_t>(-(__float_as_int(q1.z) + 1));
             leafCount = leafTriCount(__float_as_uint(q1.w));
             coneSkips = COUNT && FRONT_ONLY && coneAllBackFacing(__float_as_uint(q1.w), d);
-            boundsSkip = COUNT && missesLeafBounds(S.nodes, pend1, o, r);
-            pend1 = pend2; pend2 = pend3; pend3 = NONE;
+            boundsSkip = COUNT && missesLeafBounds<false>(S.nodes, pend1, o, d, r);
+            pend1 = pend2; pend2 = pend3; pend3 = pend4; pend4 = NONE;
         }
 
         // ---- phase 2: the leaf's triangles, src/bsp.hpp:58-104 -------------------------------------
@@ -1915,6 +1928,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
                 out.lo[k] = lf;
                 out.hi[k] = hf;
             }
+            out.index = static_cast<int32_t>(node.aux);          // the cone word, for the kernels that test cone and bounds together
         }
     }
     std::vector<float> triNormals;
