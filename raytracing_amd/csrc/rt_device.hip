@@ -304,6 +304,13 @@ struct HitRec {
 //   load(i, o, d)        reads line i of the stream
 //   store(i, hit, o, d)  receives its nearest hit (hit.ref == 0xFFFFFFFF: none)
 #define RT_FETCH_CHUNK 64u
+// The persistent kernels deal most of the stream out statically, which assumes that every block of the grid is resident.
+// The grid is sized from hipOccupancyMaxActiveBlocksPerMultiprocessor, and that answer does not see everything: on this
+// system a wave's scalar registers are allocated with 16 more than the kernel's own (trap handler), so a kernel with
+// more than 80 gets seven waves per SIMD where the query and the compiler's report both say eight.  The eighth block
+// of every CU then runs after the others and the launch takes 30 % longer (32.1 -> 42.0 ms on a 0.9 M-triangle scene
+// for two scalar registers more).  Hence the cap, under which the compiler spills to vector lanes instead.
+#define RT_PERSISTENT_SGPRS __attribute__((amdgpu_num_sgpr(82)))          // reported as "TotalSGPRs: 80"
 template <bool FRONT_ONLY, bool COUNT, bool SPILL, class Load, class Store>
 __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint32_t* __restrict__ nextLine, float tMin,
                                             Counters& c, Load load, Store store) {
@@ -1028,7 +1035,7 @@ __device__ __forceinline__ void flushCounters(const Counters& c, Counters* g) {
 
 // rt_intersect: one lane per line.
 template <bool FRONT_ONLY, bool SPILL>
-__global__ __launch_bounds__(RT_BLOCK) void k_intersect(DevScene S, const float* __restrict__ origins,
+__global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS void k_intersect(DevScene S, const float* __restrict__ origins,
                                                         const float* __restrict__ directions, uint32_t n,
                                                         float tMin, rt_hit* __restrict__ out,
                                                         uint32_t* __restrict__ nextLine) {
@@ -1057,7 +1064,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DevScene S, const float*
 }
 
 template <bool FRONT_ONLY, bool SPILL, bool MERGED>
-__global__ __launch_bounds__(RT_BLOCK) void k_intersect_bvh(DevScene S, const float* __restrict__ origins,
+__global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS void k_intersect_bvh(DevScene S, const float* __restrict__ origins,
                                                             const float* __restrict__ directions, uint32_t n,
                                                             float tMin, rt_hit* __restrict__ out,
                                                             uint32_t* __restrict__ nextLine) {
@@ -1179,7 +1186,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P,
 // counts[RT_FETCH_BASE + bounce] is this launch's line-fetch cursor (zeroed with the counts).
 #define RT_FETCH_BASE 512u
 template <bool COUNT, bool SPILL>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, PathState P, uint32_t bounce, float tMin,
+__global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS void k_trace(DevScene S, PathState P, uint32_t bounce, float tMin,
                                                     Counters* __restrict__ gc) {
     uint32_t const n = P.counts[bounce];
     uint32_t const* __restrict__ q = P.queue[bounce & 1];
@@ -1201,7 +1208,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, PathState P, uin
 
 // The same query answered from the bounding volume hierarchy (S.nodes, S.leafTris, S.leafIds then describe it).
 template <bool COUNT, bool SPILL, bool MERGED>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_bvh(DevScene S, PathState P, uint32_t bounce, float tMin,
+__global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS void k_trace_bvh(DevScene S, PathState P, uint32_t bounce, float tMin,
                                                         Counters* __restrict__ gc) {
     uint32_t const n = P.counts[bounce];
     uint32_t const* __restrict__ q = P.queue[bounce & 1];
