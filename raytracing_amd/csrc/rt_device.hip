@@ -316,7 +316,6 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                                             Counters& c, Load load, Store store) {
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t const lane = threadIdx.x & 63u;
-    unsigned long long const below = (1ull << lane) - 1ull;
     // The stack of deferred far children: the first RT_LDS_STACK_DEPTH entries live in LDS, one column
     // per lane (entry i of lane l at [i][l]: conflict-free); deeper entries, possible only in trees
     // deeper than that (SPILL), go to scratch memory.
@@ -372,7 +371,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 chunkEnd = min(base + RT_FETCH_CHUNK, n);
             }
             uint32_t const avail = chunkEnd - chunkNext;
-            uint32_t const rank = static_cast<uint32_t>(__popcll(idle & below));
+            uint32_t const rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));      // idle lanes below this one
             if (!active && rank < avail) {
                 line = chunkNext + rank;
                 load(line, o, d);
@@ -677,7 +676,6 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
                                                Counters& c, Load load, Store store) {
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t const lane = threadIdx.x & 63u;
-    unsigned long long const below = (1ull << lane) - 1ull;
     __shared__ uint32_t ldsStackBvh[RT_BVH_LDS_STACK * RT_BLOCK];
     uint32_t spillStack[SPILL ? RT_STACK_MAX - RT_BVH_LDS_STACK : 1];
     uint32_t* const stack = ldsStackBvh + threadIdx.x;
@@ -731,7 +729,7 @@ __device__ __forceinline__ void traceStreamBvh(const DevScene& S, uint32_t n, ui
                 chunkEnd = min(base + RT_FETCH_CHUNK, n);
             }
             uint32_t const avail = chunkEnd - chunkNext;
-            uint32_t const rank = static_cast<uint32_t>(__popcll(idle & below));
+            uint32_t const rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));      // idle lanes below this one
             if (!active && rank < avail) {
                 line = chunkNext + rank;
                 load(line, o, d);
