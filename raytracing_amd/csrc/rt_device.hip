@@ -345,8 +345,6 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
     int sp = 0;
     V3 o = mk(0.0f, 0.0f, 0.0f), d = o, r = o;
     float mu = INFINITY;
-    HitRec best;
-    best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
 #ifdef RT_DIAG
     unsigned long long diag[16] = {};
 #endif
@@ -379,7 +377,6 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                 mu = filterMargin(o, d, r, S.boxAbsMax);
                 sp = 0; cur = 0;
                 pend1 = NONE; pend2 = NONE; pend3 = NONE; pend4 = NONE;
-                best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
                 active = true;
             }
             chunkNext += min(static_cast<uint32_t>(__popcll(idle)), avail);
@@ -522,6 +519,10 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
         // arithmetic of the reference's scan.  Splitting keeps the long tail of the test out of the loop
         // that all lanes share: it would otherwise be issued for a handful of lanes on almost every
         // triangle.
+        // The search ends with the first leaf that yields an accepted hit (src/bsp.hpp:136-138), so the best hit so far is
+        // always "none" when a scan begins: it lives from here to the store below, not across the walk.
+        HitRec best;
+        best.t = INFINITY; best.u = 0.0f; best.v = 0.0f; best.ref = NONE;
         bool has = false;
         DIAG_T(t3);
         DIAG_ADD(2, t3 - t2);
