@@ -140,8 +140,9 @@ __device__ __forceinline__ bool lineBox(V3 o, V3 d, V3 lo, V3 hi) {
 
 // ---- conservative filter in front of the six-face test ---------------------------------------------
 // The six-face test is ~110 VALU operations; most (line, box) pairs are nowhere near its decision
-// boundary.  boxFilter decides those from the slab crossing times T = (plane - origin) * RN(1/direction)
-// (~35 operations) and leaves the rest to the exact test, so the result is always the reference's.
+// boundary.  boxFilter decides those from the slab crossing times T = plane * r - origin * r, r = RN(1/direction),
+// each one fused multiply-add on a product rounded once per line (~30 operations), and leaves the rest to the exact
+// test, so the result is always the reference's.
 //
 // Why a sure decision equals the reference's.  The reference evaluates a face of axis a at
 // t~ = RN(RN(numerator)/denominator), which differs from the exact crossing time only by a relative
@@ -150,7 +151,8 @@ __device__ __forceinline__ bool lineBox(V3 o, V3 d, V3 lo, V3 hi) {
 // m = 2^-20 (largest |box coordinate| + largest |origin coordinate|), a position at least m inside
 // (outside) the slab is therefore accepted (rejected), i.e. in time units a crossing time at least
 // m |1/d_b| inside (outside) the slab's crossing interval; mu = m max_k |1/d_k| bounds that for every
-// axis.  The T's carry a relative error below 2^-22, covered by the 2^-20 |T| terms.
+// axis.  The T's carry a relative error below 2^-22, covered by the 2^-20 |T| terms, plus 2^-24 |origin * r| from the
+// rounded product, a sixteenth of mu at most.
 //   surely meets:  the exit face (smallest far crossing time tX) has tX > theta, the line is inside the
 //     two other slabs at tX by more than theta (tX - tE > theta and second-smallest far time - tX >
 //     theta), and no direction component is below 2^-16 (else mu = inf): that face's test is true.
@@ -170,10 +172,12 @@ __device__ __forceinline__ float filterMargin(V3 o, V3 d, V3 r, float boxAbsMax)
 
 // Bit 0: surely meets; bit 1: surely misses; bit 2: the exit face is clear of the other two slabs' far
 // planes (used by the origin-inside rule below).
-__device__ __forceinline__ int boxFilter(V3 o, V3 r, float mu, V3 lo, V3 hi) {
-    float const ax = (lo.x - o.x) * r.x, bx = (hi.x - o.x) * r.x;
-    float const ay = (lo.y - o.y) * r.y, by = (hi.y - o.y) * r.y;
-    float const az = (lo.z - o.z) * r.z, bz = (hi.z - o.z) * r.z;
+__device__ __forceinline__ int boxFilter(V3 nor, V3 r, float mu, V3 lo, V3 hi) {
+    // nor = -(o * r), rounded once per line: a crossing time is one fused multiply-add, plane * r - o * r.  Its error,
+    // 2^-24 |o r| from the rounding of nor, is a sixteenth of the margin mu = 2^-20 (|box| + |o|) max|r| it is judged with.
+    float const ax = __fmaf_rn(lo.x, r.x, nor.x), bx = __fmaf_rn(hi.x, r.x, nor.x);
+    float const ay = __fmaf_rn(lo.y, r.y, nor.y), by = __fmaf_rn(hi.y, r.y, nor.y);
+    float const az = __fmaf_rn(lo.z, r.z, nor.z), bz = __fmaf_rn(hi.z, r.z, nor.z);
     float const tE = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float const xx = fmaxf(ax, bx), xy = fmaxf(ay, by), xz = fmaxf(az, bz);
     float const tX = fminf(fminf(xx, xy), xz);
@@ -394,6 +398,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
         // If the first leaf yields a hit that work is discarded, otherwise it is already done; the
         // sequence of leaves scanned is unchanged.  Kernels that count work do not look ahead, so
         // that they count exactly the visits of the reference.
+        V3 const nor = mk(-(o.x * r.x), -(o.y * r.y), -(o.z * r.z));       // for boxFilter; recomputed here so that it is not live across the scan
         while (cur != NONE && pend4 == NONE) {
             if (!COUNT) { if (__ballot(pend1 == NONE) == 0ull) break; }
             DIAG_LANES(6, 7);
@@ -404,7 +409,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             if (COUNT) c.boxTests++;
             int const index = __float_as_int(q1.z);
             uint32_t const aux = __float_as_uint(q1.w);
-            int const filterBits = boxFilter(o, r, mu, nlo, nhi);
+            int const filterBits = boxFilter(nor, r, mu, nlo, nhi);
             bool meets = (filterBits & 1) != 0;
             bool decided = (filterBits & 3) != 0;
             if (COUNT || !decided) {

@@ -22,8 +22,11 @@ def filter_decisions(o, d, lo, hi, mbox):
         rmax = np.abs(r).max(axis=1)
         ok = (np.abs(d).min(axis=1) >= f32(2.0 ** -16)) & (np.abs(d).max(axis=1) < f32(np.inf))
         mu = np.where(ok, (m * rmax).astype(f32), f32(np.inf)).astype(f32)
-        a = ((lo - o).astype(f32) * r).astype(f32)
-        b = ((hi - o).astype(f32) * r).astype(f32)
+        # crossing times as the kernel forms them: fma(plane, r, nor) with nor = -(o * r) rounded once.  (The fused
+        # multiply-add is emulated in float64, where the product of two float32 values is exact.)
+        nor = (-(o * r)).astype(f32)
+        a = (lo.astype(np.float64) * r + nor).astype(f32)
+        b = (hi.astype(np.float64) * r + nor).astype(f32)
         te = np.minimum(a, b); tx = np.maximum(a, b)
         tE = te.max(axis=1); tX = tx.min(axis=1)
         med = np.sort(tx, axis=1)[:, 1]
