@@ -536,13 +536,16 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             for (uint32_t window = 0; window < leafCount; window += 32u) {
                 uint32_t const windowEnd = min(leafCount, window + 32u);
                 uint32_t candidates = 0;
+                float4 aNext = S.leafTris[3 * static_cast<size_t>(leafFirst + window)];
                 for (uint32_t j = window; j < windowEnd; ++j) {
                     DIAG_LANES(8, 9);
                     float4 const* tp = S.leafTris + 3 * static_cast<size_t>(leafFirst + j);
                     // The facing test needs only the first 16 bytes of the record; lanes that fail it
-                    // do not fetch the rest.
-                    float4 a = tp[0];
+                    // do not fetch the rest.  Those 16 bytes are fetched one triangle ahead, so that an iteration waits for
+                    // memory once and not twice (the array ends with a spare record for the last fetch ahead).
+                    float4 a = aNext;
                     asm volatile("" : "+v"(a.w));       // keep the first fetch one 16-byte load
+                    aNext = tp[3];
                     V3 const nrm = mk(a.x, a.y, a.z);
                     float const negDet = dotF(nrm, d);
                     bool const detOk = FRONT_ONLY ? (negDet <= -1e-6f) : (fabsf(negDet) >= 1e-6f);
@@ -1873,7 +1876,8 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     if (nodes.size() > 0x7FFFFFFFull) return fail(RT_ERR_LIMIT, "rt_scene_create: too many nodes");
 
     // ---- leaf triangle records and per-triangle normals ---------------------------------------
-    std::vector<float> leafTris(12 * static_cast<size_t>(std::max<uint32_t>(refCount, 1)));
+    // one spare record at the end: the leaf scan fetches the head of the next record while it works on one
+    std::vector<float> leafTris(12 * (static_cast<size_t>(std::max<uint32_t>(refCount, 1)) + 1), 0.0f);
     std::vector<uint32_t> leafIds(4 * static_cast<size_t>(std::max<uint32_t>(refCount, 1)), 0u);
     for (uint32_t r = 0; r < refCount; ++r) {
         rt_tri_ref const ref = D->leaf_refs[r];
