@@ -253,9 +253,11 @@ __device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
 // WITH_CONE: the leaf's normal cone (coneAllBackFacing; a copy of the leaf's cone word sits in the third word of the
 // record's second half) is tested in the same breath.
 template <bool WITH_CONE>
-__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r) {
+__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r, uint32_t& coneWord, int& leafIndex) {
     const float4* bp = nodes - 2 * (static_cast<size_t>(slot) + 1);
     float4 const b0 = bp[0], b1 = bp[1];
+    coneWord = __float_as_uint(b1.z);
+    leafIndex = __float_as_int(b1.w);
     float const ax = (b0.x - o.x) * r.x, bx = (b0.w - o.x) * r.x;
     float const ay = (b0.y - o.y) * r.y, by = (b1.x - o.y) * r.y;
     float const az = (b0.z - o.z) * r.z, bz = (b1.y - o.z) * r.z;
@@ -264,6 +266,11 @@ __device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ node
     bool miss = tn - fabsf(tn) * 0x1p-16f > tf + fabsf(tf) * 0x1p-16f;
     if (WITH_CONE) miss = miss || coneAllBackFacing(__float_as_uint(b1.z), d);
     return miss;
+}
+template <bool WITH_CONE>
+__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r) {
+    uint32_t coneWord; int leafIndex;
+    return missesLeafBounds<WITH_CONE>(nodes, slot, o, d, r, coneWord, leafIndex);
 }
 
 // Diagnostic build only (-DRT_DIAG, make diag): per-phase cycle and lane-occupancy tallies of traceStream.
@@ -480,7 +487,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
 
         DIAG_T(t2);
         DIAG_ADD(1, t2 - t1);
-        uint32_t leafFirst = 0, leafCount = 0;
+        uint32_t leafFirst = 0, leafCount = 0, leafSlot = 0;
         bool coneSkips = false;           // counting kernels: the cone says "skip", to be checked against every triangle
         bool boundsSkip = false;          // counting kernels: the triangle bounds say "skip", to be checked against every accepted hit
         V3 lo = mk(0.0f, 0.0f, 0.0f), hi = lo;
@@ -490,22 +497,32 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             // loop the test would be issued for the two or three lanes that stand on a leaf, on almost every iteration.
             // Branch-free per lane (a lane without a leaf tests slot 0 and ignores the answer): every level of divergent
             // control flow holds two scalar registers, which this kernel does not have to spare, see missesLeafBounds.
-            bool drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r) && pend1 != NONE;
+            // The bounds record repeats the leaf's cone word and triangle index, so the leaf's node record is not needed
+            // before a candidate hit is checked against the leaf's box: a lane's last test is the one of the leaf it keeps
+            // (a test runs whenever some lane dropped a leaf, and a lane that dropped none repeats its own).
+            uint32_t word = 0; int leafIndex = -1;
+            bool drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, word, leafIndex) && pend1 != NONE;
             pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
             if (__ballot(drop) != 0ull) {
-                drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r) && pend1 != NONE;
+                drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, word, leafIndex) && pend1 != NONE;
                 pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                 if (__ballot(drop) != 0ull) {
-                    drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r) && pend1 != NONE;
+                    drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, word, leafIndex) && pend1 != NONE;
                     pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                     if (__ballot(drop) != 0ull) {
-                        drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r) && pend1 != NONE;
+                        drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, word, leafIndex) && pend1 != NONE;
                         pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                     }
                 }
             }
+            if (pend1 != NONE) {
+                leafFirst = static_cast<uint32_t>(-(leafIndex + 1));
+                leafCount = leafTriCount(word);
+                leafSlot = pend1;
+                pend1 = pend2; pend2 = pend3; pend3 = pend4; pend4 = NONE;
+            }
         }
-        if (pend1 != NONE) {
+        else if (pend1 != NONE) {
             float4 const q0 = S.nodes[2 * pend1];
             float4 const q1 = S.nodes[2 * pend1 + 1];
             lo = mk(q0.x, q0.y, q0.z); hi = mk(q0.w, q1.x, q1.y);
@@ -576,6 +593,11 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
                     candidates &= candidates - 1u;
                     float4 const* tp = S.leafTris + 3 * static_cast<size_t>(leafFirst + j);
                     float4 const a = tp[0], b = tp[1], e = tp[2];
+                    if (!COUNT) {
+                        float4 const q0 = S.nodes[2 * leafSlot];
+                        float4 const q1 = S.nodes[2 * leafSlot + 1];
+                        lo = mk(q0.x, q0.y, q0.z); hi = mk(q0.w, q1.x, q1.y);
+                    }
                     V3 const nrm = mk(a.x, a.y, a.z);
                     float const negDet = dotF(nrm, d);
                     V3 const v1 = mk(a.w, b.x, b.y), e13 = mk(b.z, b.w, e.x), e12 = mk(e.y, e.z, e.w);
@@ -1943,7 +1965,8 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
                 out.lo[k] = lf;
                 out.hi[k] = hf;
             }
-            out.index = static_cast<int32_t>(node.aux);          // the cone word, for the kernels that test cone and bounds together
+            out.index = static_cast<int32_t>(node.aux);          // the leaf's cone word and triangle index: the kernels start the
+            out.aux = static_cast<uint32_t>(node.index);         // scan from this record alone
         }
     }
     std::vector<float> triNormals;
