@@ -246,12 +246,13 @@ __device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
 // NaN (0 * inf on an axis-parallel line) makes the comparison false, i.e. no skip.  Kernels that count work scan every
 // leaf and count an accepted hit in a leaf these bounds would have skipped as an error (rt_stats.box_filter_errors).
 //
-// The record of slot s sits at nodes[-(s + 1)] (32 bytes, {lo.xyz, hi.x} {hi.yz, cone word, -}): the bounds are stored in
+// The record of slot s sits at nodes[-(s + 1)] (32 bytes, {lo.xyz, hi.x} {hi.yz, cone word, index}): the bounds are stored in
 // front of the node array, mirrored, so that the kernel needs no second base address.  That matters: the traversal
 // kernel for deep trees sits at 80 scalar registers, and with two more its time on a 0.9 M-triangle scene goes from 32
 // to 42 ms whatever the extra registers are used for.
-// WITH_CONE: the leaf's normal cone (coneAllBackFacing; a copy of the leaf's cone word sits in the third word of the
-// record's second half) is tested in the same breath.
+// The record ends with copies of the leaf's cone word and index (its first triangle), which are handed out: a leaf that
+// is kept is scanned from this record alone.  WITH_CONE: the leaf's normal cone (coneAllBackFacing) is tested in the
+// same breath.
 template <bool WITH_CONE>
 __device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r, uint32_t& coneWord, int& leafIndex) {
     const float4* bp = nodes - 2 * (static_cast<size_t>(slot) + 1);
