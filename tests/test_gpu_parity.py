@@ -883,3 +883,64 @@ def test_random_soups_at_many_scales_bit_exact(oracle_lib, scale, offset):
         _assert_same_image_and_work(img, st, oimg, ost)
     finally:
         ds.close(); osc.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_degenerate_soups_bit_exact(oracle_lib, seed):
+    """Geometry that sits where the shortcuts are weakest: zero-area triangles, needles that cross many leaves,
+    exact duplicates (equal t: the ascending scan with strict < decides), and axis-aligned triangles whose
+    coordinates are multiples of 1/2, so that they lie in the tree's split planes and on leaf-box faces (the leaf
+    triangle bounds are then flat in one axis).  Lines: random ones, axis-parallel ones that start on those planes,
+    and lines that run inside them.  Hits, image and work counters must equal the oracle's."""
+    rng = np.random.default_rng(seed)
+    n = 1600
+    centres = rng.uniform(-4, 4, (n, 1, 3))
+    v = centres + rng.uniform(-0.4, 0.4, (n, 3, 3))
+    kind = rng.integers(0, 5, n)
+    v[kind == 0, 2] = v[kind == 0, 1]                                         # zero area
+    v[kind == 1, 2] = v[kind == 1, 0] + rng.uniform(-6, 6, ((kind == 1).sum(), 3))   # needles
+    snapped = np.round(v[kind == 2] * 2.0) / 2.0                              # grid-aligned ...
+    axis = rng.integers(0, 3, len(snapped))
+    snapped[np.arange(len(snapped)), :, axis] = snapped[np.arange(len(snapped)), :1, axis]   # ... and flat in one axis
+    snapped[:, 1, (axis[0] + 1) % 3] += 0.5                                   # keep most of them non-degenerate
+    snapped[:, 2, (axis[0] + 2) % 3] += 0.5
+    v[kind == 2] = snapped
+    dup = np.nonzero(kind == 3)[0]
+    v[dup] = v[rng.integers(0, n, len(dup))]                                  # duplicates of other triangles
+    v[0] = [[-4.5, -4.5, -4.5], [4.5, -4.5, -4.5], [-4.5, 4.5, 4.5]]            # pins the box to multiples of 1/2
+    v[1] = [[4.5, 4.5, 4.5], [-4.5, 4.5, 4.5], [4.5, -4.5, -4.5]]
+    pos = v.reshape(-1, 3).astype(np.float32)
+    nrm = rng.standard_normal((len(pos), 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    tris = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    m = S.Models()
+    m.add(S.MeshTransform((0, 0, 0), S.IDENTITY_QUAT, (1, 1, 1)), 0, 0)
+    cam = S.Camera((0.25, 0.5, 13.0), (0, np.pi, 0), 0.8)
+    mats = [S.Material((0.6, 0.5, 0.4), 0.4, 0.2, (0.5, 0.4, 0.3))]
+    sc = S.Scene(cam, S.Meshes([(pos, nrm, tris)]), mats, m, inflate_mode=1)
+    ds, osc = _pair(oracle_lib, sc, 96, 64)
+    try:
+        k = 12000
+        o = rng.uniform(-5.5, 5.5, (k, 3))
+        d = rng.standard_normal((k, 3))
+        # a third of the lines start on grid planes, a third are axis-parallel (some of them both: they run inside a plane)
+        onGrid = rng.random(k) < 0.33
+        o[onGrid] = np.round(o[onGrid] * 2.0) / 2.0
+        par = rng.random(k) < 0.33
+        ax = rng.integers(0, 3, k)
+        dpar = np.zeros((k, 3)); dpar[np.arange(k), ax] = rng.choice([-1.0, 1.0], k)
+        two = rng.random(k) < 0.5                                               # in-plane diagonals as well
+        dpar[np.arange(k), (ax + 1) % 3] = np.where(two, rng.choice([-1.0, 1.0], k), 0.0)
+        d[par] = dpar[par]
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True))
+        o = o.astype(np.float32); d = d.astype(np.float32)
+        hits = 0
+        for front in (True, False):
+            f, ids = osc.intersect(o, d, 1e-3, front)
+            _check_hits(ds.intersect(o, d, 1e-3, front), f, ids)
+            hits += int((ids[:, 0] != 0xFFFFFFFF).sum())
+        assert hits > k // 10
+        img, st, oimg, ost = _render_both(ds, osc, sc, 96, 64, spp=3, seed=seed)
+        _assert_same_image_and_work(img, st, oimg, ost)
+    finally:
+        ds.close(); osc.close()
