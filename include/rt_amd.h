@@ -244,6 +244,18 @@ int rt_postprocess(int device, const float* hdr, uint32_t width, uint32_t height
  * 4 fma(a,b,a), 5 a*b+a unfused.  Not part of the rendering interface. */
 int rt_selftest_math(int op, const float* a, const float* b, uint32_t n, float* out);
 
+/* Test hooks for the leaf triangle bounds (host only, no GPU; no counterpart in the reference, which scans every leaf
+ * its line enters, src/bsp.hpp:106-117).  rt_debug_flatten returns the node and leaf bounds records exactly as
+ * rt_scene_create uploads them: 12 floats per bounds record (the record of node slot s at float offset
+ * 12 * (front_slots - 1 - s): lo[3], hi[3], cone word, leaf index, cK, cE, 0, 0), then 8 floats per node record (slot
+ * s at 12 * front_slots + 8 * s: lo[3], hi[3], index, aux).  With packed == NULL only the sizes are returned.
+ * rt_debug_leaf_drop evaluates, on the host and with the kernels' own arithmetic, whether the traversal would leave
+ * the leaf at node slot slots[i] unscanned for line i (1) or scan it (0). */
+int rt_debug_flatten(const rt_scene_desc* desc, float* packed, uint64_t* packed_floats, uint32_t* node_slots,
+                     uint32_t* front_slots, float* box_abs_max);
+int rt_debug_leaf_drop(const float* packed, uint32_t front_slots, float box_abs_max, const uint32_t* slots,
+                       const float* origins, const float* directions, uint64_t n, uint8_t* out_drop);
+
 const char* rt_last_error(void);
 /* Library/ABI version, bumped on any layout change of the structs above. */
 uint32_t rt_abi_version(void);

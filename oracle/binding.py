@@ -252,6 +252,21 @@ class Scene:
                                        _c.c_int(int(bool(front_only))), _p(f), _p(ids))
         return f, ids
 
+    def leaf_hits(self, leaves, boxes, origins, directions, t_min=1e-3, front_only=True):
+        """C oracle only: visitLeaf alone (src/bsp.hpp:58-104) for line i against leaf leaves[i] with box boxes[i]."""
+        assert not self.L.is_ref
+        lv = np.ascontiguousarray(leaves, np.uint32)
+        bx = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(directions, np.float32)
+        n = o.shape[0]
+        assert len(lv) == n and len(bx) == n
+        out = np.zeros(n, np.uint8)
+        t = np.zeros(n, np.float32)
+        self.L.lib.orc_leaf_hits(self.h, _p(lv), _p(bx), _p(o), _p(d), _c.c_size_t(n), _c.c_float(t_min),
+                                 _c.c_int(int(bool(front_only))), _p(out), _p(t))
+        return out.astype(bool), t
+
     def set_bvh4(self, nodes, tri_order):
         """C oracle only: hand over the product's bounding volume hierarchy (64-byte nodes, triangle order) for the
         restated traversal (intersect(use_bvh=True), render_params(flags=FLAG_ACCEL_BVH))."""

@@ -915,6 +915,22 @@ void orc_intersect(const orc_scene* s, const float* origins, const float* direct
     }
 }
 
+/* BSPTree::lineTriNearestIntersection's visitLeaf alone (src/bsp.hpp:58-104): for line i, does the scan of leaf
+ * leaves[i] (an index into the tree's leaf array) with the leaf box boxes[6 i ..] (min xyz, max xyz: Node::box of the
+ * node that refers to the leaf, src/bsp.hpp:148-153) yield a hit?  out[i] = 1 or 0; outT[i] its t.  Used to check,
+ * leaf by leaf, the product's rule for leaving a leaf unscanned. */
+void orc_leaf_hits(const orc_scene* s, const uint32_t* leaves, const float* boxes, const float* origins, const float* directions,
+                   size_t n, float tMin, int frontOnly, uint8_t* out, float* outT) {
+    for (size_t i = 0; i < n; ++i) {
+        traverser tr = {s, ld3(origins + 3 * i), ld3(directions + 3 * i), tMin, frontOnly & 1, NULL};
+        box3 box = {ld3(boxes + 6 * i), ld3(boxes + 6 * i + 3)};
+        hit_rec h;
+        h.t = 0.0f;
+        out[i] = (leaves[i] < s->leafCount && visit_leaf(&tr, &box, &s->leaves[leaves[i]], &h)) ? 1 : 0;
+        if (outT) outT[i] = out[i] ? h.t : 0.0f;
+    }
+}
+
 /* src/render.hpp:227: normalize(pixelToRay * vec3{sx, sy, 1}) with glm's mat3*vec3
  * (libraries/glm/glm/detail/type_mat3x3.inl:468-474). */
 static inline v3 camera_ray(const float* m, float sx, float sy) {

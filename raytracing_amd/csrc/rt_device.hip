@@ -8,6 +8,8 @@
 // correctly rounded forms.
 #include "rt_amd.h"
 #include "rt_host.h"
+#include "rt_flatten.h"
+#include "rt_leaf_bounds.h"
 
 #include <hip/hip_runtime.h>
 
@@ -163,11 +165,7 @@ __device__ __forceinline__ bool lineBox(V3 o, V3 d, V3 lo, V3 hi) {
 // tools/box_filter_check.py replays this arithmetic on the CPU against the exact test; kernels built
 // with COUNT evaluate both on every box and count disagreements (rt_stats.box_filter_errors).
 __device__ __forceinline__ float filterMargin(V3 o, V3 d, V3 r, float boxAbsMax) {
-    float const m = 0x1p-20f * (boxAbsMax + fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)));
-    float const dMin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-    float const dMax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-    float const rMax = fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fabsf(r.z));
-    return (dMin >= 0x1p-16f && dMax < INFINITY) ? m * rMax : INFINITY;      // false for NaN components too
+    return rtFilterMargin(o.x, o.y, o.z, d.x, d.y, d.z, r.x, r.y, r.z, boxAbsMax);      // rt_leaf_bounds.h
 }
 
 // Bit 0: surely meets; bit 1: surely misses; bit 2: the exit face is clear of the other two slabs' far
@@ -239,39 +237,35 @@ __device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
 // A leaf's box is a cell of the spatial subdivision; its triangles usually fill a fraction of it (0.4-0.5 of the volume
 // on the benchmark scenes), and half of the leaves a line enters (and whose cone does not already exclude them) it
 // leaves without coming near a triangle.  The scene therefore keeps, per leaf, the bounds of the triangles AS THE TEST
-// SEES THEM (v1, v1 + v1ToV2, v1 + v1ToV3) clipped to the leaf's box and padded by 2^-18 of the largest box coordinate,
-// rounded outwards.  An accepted hit lies on a triangle (barycentric test) and in the leaf's box (src/bsp.hpp:82-87),
-// both up to roundings far smaller than the padding, so a line that misses these bounds has no accepted hit in the leaf
-// and the leaf need not be scanned: same result as scanning it.  The interval ends are widened by 2^-16 relative; a
-// NaN (0 * inf on an axis-parallel line) makes the comparison false, i.e. no skip.  Kernels that count work scan every
-// leaf and count an accepted hit in a leaf these bounds would have skipped as an error (rt_stats.box_filter_errors).
+// SEES THEM (v1, v1 + v1ToV2, v1 + v1ToV3) clipped to the leaf's box, and a leaf whose bounds the line misses by a margin
+// that grows as the line approaches the triangles' planes is not scanned.  The rule and the proof that such a leaf holds
+// no hit the reference would accept are in rt_leaf_bounds.h (rtLeafBoundsMiss); `rayOk` is "the line's filter margin is
+// finite".  Kernels that count work scan every leaf and count an accepted hit in a leaf the rule would have dropped
+// as an error (rt_stats.box_filter_errors).
 //
-// The record of slot s sits at nodes[-(s + 1)] (32 bytes, {lo.xyz, hi.x} {hi.yz, cone word, index}): the bounds are stored in
-// front of the node array, mirrored, so that the kernel needs no second base address.  That matters: the traversal
-// kernel for deep trees sits at 80 scalar registers, and with two more its time on a 0.9 M-triangle scene goes from 32
-// to 42 ms whatever the extra registers are used for.
-// The record ends with copies of the leaf's cone word and index (its first triangle), which are handed out: a leaf that
+// The record of slot s sits at nodes[-3 (s + 1)] (48 bytes, {lo.xyz, hi.x} {hi.yz, cone word, index} {cK, cE, -, -}): the
+// bounds are stored in front of the node array, mirrored, so that the kernel needs no second base address.  That matters:
+// the traversal kernel for deep trees sits at 80 scalar registers, and with two more its time on a 0.9 M-triangle scene
+// goes from 32 to 42 ms whatever the extra registers are used for.
+// The record carries copies of the leaf's cone word and index (its first triangle), which are handed out: a leaf that
 // is kept is scanned from this record alone.  WITH_CONE: the leaf's normal cone (coneAllBackFacing) is tested in the
 // same breath.
 template <bool WITH_CONE>
-__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r, uint32_t& coneWord, int& leafIndex) {
-    const float4* bp = nodes - 2 * (static_cast<size_t>(slot) + 1);
+__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r, bool rayOk, uint32_t& coneWord, int& leafIndex) {
+    const float4* bp = nodes - 3 * (static_cast<size_t>(slot) + 1);
     float4 const b0 = bp[0], b1 = bp[1];
+    float2 const b2 = *reinterpret_cast<const float2*>(bp + 2);
     coneWord = __float_as_uint(b1.z);
     leafIndex = __float_as_int(b1.w);
-    float const ax = (b0.x - o.x) * r.x, bx = (b0.w - o.x) * r.x;
-    float const ay = (b0.y - o.y) * r.y, by = (b1.x - o.y) * r.y;
-    float const az = (b0.z - o.z) * r.z, bz = (b1.y - o.z) * r.z;
-    float const tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    float const tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    bool miss = tn - fabsf(tn) * 0x1p-16f > tf + fabsf(tf) * 0x1p-16f;
+    bool miss = rtLeafBoundsMiss(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, __float_as_uint(b1.z), b2.x, b2.y, o.x, o.y, o.z, d.x, d.y, d.z,
+                                 r.x, r.y, r.z, rayOk);
     if (WITH_CONE) miss = miss || coneAllBackFacing(__float_as_uint(b1.z), d);
     return miss;
 }
 template <bool WITH_CONE>
-__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r) {
+__device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r, bool rayOk) {
     uint32_t coneWord; int leafIndex;
-    return missesLeafBounds<WITH_CONE>(nodes, slot, o, d, r, coneWord, leafIndex);
+    return missesLeafBounds<WITH_CONE>(nodes, slot, o, d, r, rayOk, coneWord, leafIndex);
 }
 
 // Diagnostic build only (-DRT_DIAG, make diag): per-phase cycle and lane-occupancy tallies of traceStream.
@@ -502,16 +496,16 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             // before a candidate hit is checked against the leaf's box: a lane's last test is the one of the leaf it keeps
             // (a test runs whenever some lane dropped a leaf, and a lane that dropped none repeats its own).
             uint32_t word = 0; int leafIndex = -1;
-            bool drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, word, leafIndex) && pend1 != NONE;
+            bool drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
             pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
             if (__ballot(drop) != 0ull) {
-                drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, word, leafIndex) && pend1 != NONE;
+                drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
                 pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                 if (__ballot(drop) != 0ull) {
-                    drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, word, leafIndex) && pend1 != NONE;
+                    drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
                     pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                     if (__ballot(drop) != 0ull) {
-                        drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, word, leafIndex) && pend1 != NONE;
+                        drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
                         pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                     }
                 }
@@ -530,7 +524,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             leafFirst = static_cast<uint32_t>(-(__float_as_int(q1.z) + 1));
             leafCount = leafTriCount(__float_as_uint(q1.w));
             coneSkips = COUNT && FRONT_ONLY && coneAllBackFacing(__float_as_uint(q1.w), d);
-            boundsSkip = COUNT && missesLeafBounds<false>(S.nodes, pend1, o, d, r);
+            boundsSkip = COUNT && missesLeafBounds<false>(S.nodes, pend1, o, d, r, mu < INFINITY);
             pend1 = pend2; pend2 = pend3; pend3 = pend4; pend4 = NONE;
         }
 
@@ -1745,241 +1739,17 @@ int rt_internal_fail(int code, const char* message) { return fail(code, message 
 
 namespace {
 
-// The three instantiated vertex normals of every triangle of the scene (9 floats per scene-wide triangle index),
-// RayTraceData::vertexNormals looked up through tris / triRanges / vertexRanges as src/render.hpp:121-129 does.
-int gatherTriNormals(const rt_scene_desc* D, const char* who, std::vector<float>& out) {
-    out.assign(9 * static_cast<size_t>(std::max<uint32_t>(D->pretri_count, 1)), 0.0f);
-    for (uint32_t m = 0; m < D->model_count; ++m) {
-        uint32_t const tb = D->model_pretri_begin[m], te = D->model_pretri_begin[m + 1];
-        uint32_t const vb = D->model_vertex_begin[m], ve = D->model_vertex_begin[m + 1];
-        if (te < tb || ve < vb || te > D->pretri_count || ve > D->vertex_count)
-            return fail(RT_ERR_INVALID, std::string(who) + ": offsets not ascending");
-        if (static_cast<uint64_t>(D->model_tri_begin[m]) + (te - tb) > D->base_tri_count)
-            return fail(RT_ERR_INVALID, std::string(who) + ": model triangle range outside base_tris");
-        for (uint32_t k = 0; k < te - tb; ++k) {
-            uint32_t const* idx = D->base_tris + 3 * (static_cast<size_t>(D->model_tri_begin[m]) + k);
-            float* o = out.data() + 9 * static_cast<size_t>(tb + k);
-            for (int j = 0; j < 3; ++j) {
-                if (idx[j] >= ve - vb) return fail(RT_ERR_INVALID, std::string(who) + ": vertex index outside model");
-                std::memcpy(o + 3 * j, D->vertex_normals + 3 * static_cast<size_t>(vb + idx[j]), 12);
-            }
-        }
-    }
-    return RT_OK;
-}
-
-// Cone code of a leaf (bits 8-30 of the leaf record's aux word; 0: none), from the normals that head the leaf's triangle
-// records (12 floats each).  The axis is the integer point nearest to 31 times the mean unit normal; the threshold is
-// derived from that integer axis, with 0.002 rad to spare, and rounded up to an integer.
-uint32_t leafCone(const float* records, uint32_t count) {
-    double mean[3] = {0.0, 0.0, 0.0};
-    uint32_t used = 0;
-    for (uint32_t i = 0; i < count; ++i) {
-        float const* n = records + 12 * static_cast<size_t>(i);
-        double const len = std::sqrt(double(n[0]) * n[0] + double(n[1]) * n[1] + double(n[2]) * n[2]);
-        if (!(len > 0.0) || !(len < 1e300)) {
-            if (len == 0.0) continue;            // a zero normal fails the facing test whatever the direction
-            return 0u;                           // NaN or infinite normal: no cone
-        }
-        for (int k = 0; k < 3; ++k) mean[k] += n[k] / len;
-        ++used;
-    }
-    double const meanLen = std::sqrt(mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
-    if (used == 0 || !(meanLen > 1e-6)) return 0u;
-    int axis[3];
-    for (int k = 0; k < 3; ++k)
-        axis[k] = static_cast<int>(std::min(31.0, std::max(-31.0, std::floor(mean[k] / meanLen * 31.0 + 0.5))));
-    double const axisLen = std::sqrt(double(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]));
-    if (!(axisLen > 0.0)) return 0u;
-    double spread = 0.0;
-    for (uint32_t i = 0; i < count; ++i) {
-        float const* n = records + 12 * static_cast<size_t>(i);
-        double const len = std::sqrt(double(n[0]) * n[0] + double(n[1]) * n[1] + double(n[2]) * n[2]);
-        if (len == 0.0) continue;
-        double const c = (n[0] * double(axis[0]) + n[1] * double(axis[1]) + n[2] * double(axis[2])) / (len * axisLen);
-        spread = std::max(spread, std::acos(std::min(1.0, std::max(-1.0, c))));
-    }
-    double const angle = spread + 0.002;
-    if (!(angle <= 1.53)) return 0u;
-    double const needed = std::sin(angle) * axisLen * (1.0 + 1e-6);
-    uint32_t const q = std::max(1u, static_cast<uint32_t>(std::ceil(needed)));
-    if (q > 31u) return 0u;
-    return (q << 8) | ((static_cast<uint32_t>(axis[2]) & 0x3Fu) << 13) | ((static_cast<uint32_t>(axis[1]) & 0x3Fu) << 19)
-         | ((static_cast<uint32_t>(axis[0]) & 0x3Fu) << 25);
-}
-
-// One 48-byte shading record: {model, vn1.xyz} {vn2.xyz, vn3.x} {vn3.yz, 0, 0}.
-void shadeRecord(float* rec, uint32_t model, const float* normals9) {
-    std::memcpy(rec, &model, 4);
-    std::memcpy(rec + 1, normals9, 36);
-    rec[10] = 0.0f;
-    rec[11] = 0.0f;
-}
-
 int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     if (!D || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
     *out = nullptr;
-    if (!D->model_pretri_begin || !D->model_vertex_begin || !D->leaf_first_ref)
-        return fail(RT_ERR_INVALID, "rt_scene_create: null offset array in description");
-    if ((D->model_count && (!D->model_tri_begin || !D->model_materials)) || (D->pretri_count && !D->pretris && !D->leaf_pretris)
-        || (D->vertex_count && !D->vertex_normals) || (D->base_tri_count && !D->base_tris))
-        return fail(RT_ERR_INVALID, "rt_scene_create: null array in description");
-    if (D->inode_count && !D->inodes) return fail(RT_ERR_INVALID, "rt_scene_create: inodes missing");
-    uint32_t const refCount = D->leaf_first_ref[D->leaf_count];
-    if (refCount && !D->leaf_refs) return fail(RT_ERR_INVALID, "rt_scene_create: leaf_refs missing");
-    if (D->model_pretri_begin[D->model_count] != D->pretri_count)
-        return fail(RT_ERR_INVALID, "rt_scene_create: model_pretri_begin does not end at pretri_count");
-    if (D->model_vertex_begin[D->model_count] != D->vertex_count)
-        return fail(RT_ERR_INVALID, "rt_scene_create: model_vertex_begin does not end at vertex_count");
-
-    // ---- flatten the tree -------------------------------------------------------------------
-    struct HNode { float lo[3], hi[3]; int32_t index; uint32_t aux; };
-    static_assert(sizeof(HNode) == 32, "node record must be 32 bytes");
-    std::vector<HNode> nodes;
-    nodes.reserve(2 * static_cast<size_t>(D->inode_count) + 2);
-    auto leafRecord = [&](int32_t refIndex, HNode& n) -> int {
-        uint32_t const leaf = static_cast<uint32_t>(-(refIndex + 1));
-        if (leaf >= D->leaf_count) return fail(RT_ERR_INVALID, "rt_scene_create: leaf index out of range");
-        uint32_t const a = D->leaf_first_ref[leaf], b = D->leaf_first_ref[leaf + 1];
-        if (b < a || b > refCount || b == a) return fail(RT_ERR_INVALID, "rt_scene_create: bad leaf range");
-        n.index = -static_cast<int32_t>(a) - 1;
-        n.aux = b - a;
-        return RT_OK;
-    };
-    uint32_t maxDepth = 0;
+    rt_flat_scene F;                      // rt_flatten.cpp: validation, node and leaf bounds records, triangle and shading records
     {
-        HNode root{};
-        std::memcpy(root.lo, D->root_box, 12);
-        std::memcpy(root.hi, D->root_box + 3, 12);
-        nodes.push_back(root);
-        nodes.push_back(HNode{});          // padding: child pairs then start at even slots, one pair per 64-byte line
-        struct Item { uint32_t nodeSlot; int32_t refIndex; uint32_t depth; };
-        std::vector<Item> todo;
-        todo.push_back({0u, D->root_index, 0u});
-        std::vector<uint8_t> seen(D->inode_count, 0);
-        while (!todo.empty()) {
-            Item const it = todo.back();
-            todo.pop_back();
-            maxDepth = std::max(maxDepth, it.depth);
-            if (it.refIndex == 0) { nodes[it.nodeSlot].index = 0; nodes[it.nodeSlot].aux = 0; continue; }
-            if (it.refIndex < 0) {
-                HNode tmp = nodes[it.nodeSlot];
-                int const rc = leafRecord(it.refIndex, tmp);
-                if (rc != RT_OK) return rc;
-                nodes[it.nodeSlot] = tmp;
-                continue;
-            }
-            uint32_t const inode = static_cast<uint32_t>(it.refIndex - 1);
-            if (inode >= D->inode_count) return fail(RT_ERR_INVALID, "rt_scene_create: inode index out of range");
-            if (seen[inode]) return fail(RT_ERR_INVALID, "rt_scene_create: inode referenced twice");
-            seen[inode] = 1;
-            rt_inode const& in = D->inodes[inode];
-            if (in.axis > 2) return fail(RT_ERR_INVALID, "rt_scene_create: bad division axis");
-            // The kernels recompute the split plane as the centre of the node's own box.
-            HNode const self = nodes[it.nodeSlot];
-            float const plane = (self.lo[in.axis] + self.hi[in.axis]) / 2.0f;
-            if (!(in.pos_box[in.axis] == plane))
-                return fail(RT_ERR_INVALID, "rt_scene_create: tree is not split at box centres");
-            uint32_t const pair = static_cast<uint32_t>(nodes.size());
-            nodes[it.nodeSlot].index = static_cast<int32_t>(pair);
-            nodes[it.nodeSlot].aux = in.axis | (in.neg_index == 0 ? 4u : 0u) | (in.pos_index == 0 ? 8u : 0u);
-            HNode a{}, b{};
-            std::memcpy(a.lo, in.neg_box, 12); std::memcpy(a.hi, in.neg_box + 3, 12);
-            std::memcpy(b.lo, in.pos_box, 12); std::memcpy(b.hi, in.pos_box + 3, 12);
-            nodes.push_back(a);
-            nodes.push_back(b);
-            // Depth-first, negative side first, so a subtree's records stay close together.
-            todo.push_back({pair + 1, in.pos_index, it.depth + 1});
-            todo.push_back({pair, in.neg_index, it.depth + 1});
-        }
-    }
-    if (maxDepth > RT_STACK_MAX)
-        return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth " + std::to_string(maxDepth) + " exceeds the "
-                    + std::to_string(RT_STACK_MAX) + "-entry traversal stack");
-    if (nodes.size() > 0x7FFFFFFFull) return fail(RT_ERR_LIMIT, "rt_scene_create: too many nodes");
-
-    // ---- leaf triangle records and per-triangle normals ---------------------------------------
-    // one spare record at the end: the leaf scan fetches the head of the next record while it works on one
-    std::vector<float> leafTris(12 * (static_cast<size_t>(std::max<uint32_t>(refCount, 1)) + 1), 0.0f);
-    std::vector<uint32_t> leafIds(4 * static_cast<size_t>(std::max<uint32_t>(refCount, 1)), 0u);
-    for (uint32_t r = 0; r < refCount; ++r) {
-        rt_tri_ref const ref = D->leaf_refs[r];
-        if (ref.mesh >= D->model_count) return fail(RT_ERR_INVALID, "rt_scene_create: leaf ref model out of range");
-        uint32_t const b = D->model_pretri_begin[ref.mesh], e = D->model_pretri_begin[ref.mesh + 1];
-        if (ref.tri >= e - b) return fail(RT_ERR_INVALID, "rt_scene_create: leaf ref triangle out of range");
-        uint32_t const gtri = b + ref.tri;
-        float const* pt = D->leaf_pretris ? D->leaf_pretris + 12 * static_cast<size_t>(r)
-                                          : D->pretris + 12 * static_cast<size_t>(gtri);    // normal, v1, v1ToV3, v1ToV2
-        std::memcpy(leafTris.data() + 12 * static_cast<size_t>(r), pt, 48);
-        uint32_t const ids[4] = {ref.mesh, ref.tri, gtri, 0u};
-        std::memcpy(leafIds.data() + 4 * static_cast<size_t>(r), ids, 16);
-    }
-    // ---- leaf normal cones (see coneAllBackFacing) ----------------------------------------------------
-    unsigned long long leavesSeen = 0, leavesWithCone = 0, thresholdSum = 0;
-    for (HNode& node : nodes) {
-        if (node.index >= 0) continue;
-        uint32_t const first = static_cast<uint32_t>(-(node.index + 1)), leafCount = node.aux;
-        node.aux = leafCount >= 256u ? (0x80000000u | leafCount) : (leafCount | leafCone(leafTris.data() + 12 * static_cast<size_t>(first), leafCount));
-        ++leavesSeen;
-        if ((node.aux >> 8) != 0u && (node.aux & 0x80000000u) == 0u) { ++leavesWithCone; thresholdSum += (node.aux >> 8) & 0x1Fu; }
-    }
-    if (std::getenv("RT_AMD_DEBUG"))
-        std::fprintf(stderr, "rt_amd: %llu of %llu leaves carry a normal cone, mean threshold %.3f\n", leavesWithCone, leavesSeen,
-                     leavesWithCone ? double(thresholdSum) / 31.0 / double(leavesWithCone) : 0.0);
-    // ---- leaf triangle bounds in front of the node records (see missesLeafBounds) -------------------------------
-    // packed[N + s] = node record of slot s, packed[N - 1 - s] = bounds of the leaf at slot s
-    std::vector<HNode> packed(2 * nodes.size(), HNode{});
-    {
-        size_t const N = nodes.size();
-        double absMax = 0.0;
-        for (int k = 0; k < 3; ++k) absMax = std::max(absMax, std::max(std::fabs(double(nodes[0].lo[k])), std::fabs(double(nodes[0].hi[k]))));
-        double const pad = std::ldexp(absMax, -18);
-        // RT_AMD_LEAF_BOUNDS=0 (measurements): every leaf gets unbounded bounds, which no line misses
-        bool const unbounded = std::getenv("RT_AMD_LEAF_BOUNDS") && std::atoi(std::getenv("RT_AMD_LEAF_BOUNDS")) == 0;
-        for (size_t slot = 0; slot < N; ++slot) {
-            HNode const& node = nodes[slot];
-            packed[N + slot] = node;
-            if (node.index >= 0) continue;
-            uint32_t const first = static_cast<uint32_t>(-(node.index + 1));
-            uint32_t const leafCount = (node.aux & 0x80000000u) ? (node.aux & 0x7FFFFFFFu) : (node.aux & 0xFFu);
-            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            bool finite = !unbounded;
-            for (uint32_t i = 0; i < leafCount; ++i) {
-                float const* rec = leafTris.data() + 12 * static_cast<size_t>(first + i);       // normal, v1, v1ToV3, v1ToV2
-                for (int k = 0; k < 3; ++k) {
-                    double const a = rec[3 + k], b = a + double(rec[6 + k]), c = a + double(rec[9 + k]);
-                    if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(c)) finite = false;
-                    lo[k] = std::min(lo[k], std::min(a, std::min(b, c)));
-                    hi[k] = std::max(hi[k], std::max(a, std::max(b, c)));
-                }
-            }
-            HNode& out = packed[N - 1 - slot];
-            for (int k = 0; k < 3; ++k) {
-                double l = -INFINITY, h = INFINITY;              // non-finite vertices: no bounds
-                if (finite) {
-                    l = std::max(lo[k], double(node.lo[k])) - pad;
-                    h = std::min(hi[k], double(node.hi[k])) + pad;
-                }
-                float lf = static_cast<float>(l), hf = static_cast<float>(h);
-                if (double(lf) > l) lf = std::nextafter(lf, -INFINITY);
-                if (double(hf) < h) hf = std::nextafter(hf, INFINITY);
-                out.lo[k] = lf;
-                out.hi[k] = hf;
-            }
-            out.index = static_cast<int32_t>(node.aux);          // the leaf's cone word and triangle index: the kernels start the
-            out.aux = static_cast<uint32_t>(node.index);         // scan from this record alone
-        }
-    }
-    std::vector<float> triNormals;
-    {
-        int const rc = gatherTriNormals(D, "rt_scene_create", triNormals);
+        int const rc = rt_internal_flatten(D, F);
         if (rc != RT_OK) return rc;
     }
-    // shading records in the order of the leaf triangle records
-    std::vector<float> shadeRecs(12 * static_cast<size_t>(std::max<uint32_t>(refCount, 1)), 0.0f);
-    for (uint32_t r = 0; r < refCount; ++r)
-        shadeRecord(shadeRecs.data() + 12 * static_cast<size_t>(r), leafIds[4 * static_cast<size_t>(r)],
-                    triNormals.data() + 9 * static_cast<size_t>(leafIds[4 * static_cast<size_t>(r) + 2]));
+    if (F.depth > RT_STACK_MAX)
+        return fail(RT_ERR_LIMIT, "rt_scene_create: tree depth " + std::to_string(F.depth) + " exceeds the "
+                    + std::to_string(RT_STACK_MAX) + "-entry traversal stack");
 
     // ---- upload ---------------------------------------------------------------------------------
     int count = 0;
@@ -2004,28 +1774,26 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     if (D->model_count) std::memcpy(mats.data(), D->model_materials, 48 * static_cast<size_t>(D->model_count));
     void* dCounts = nullptr;
     void* dCounters = nullptr;
-    hipError_t e = upload(&s->dNodes, packed.data(), packed.size() * sizeof(HNode));
-    if (e == hipSuccess) e = upload(&s->dLeafTris, leafTris.data(), leafTris.size() * 4);
-    if (e == hipSuccess) e = upload(&s->dLeafIds, leafIds.data(), leafIds.size() * 4);
-    if (e == hipSuccess) e = upload(&s->dTriNormals, shadeRecs.data(), shadeRecs.size() * 4);
+    hipError_t e = upload(&s->dNodes, F.packed.data(), F.packed.size() * 4);
+    if (e == hipSuccess) e = upload(&s->dLeafTris, F.leafTris.data(), F.leafTris.size() * 4);
+    if (e == hipSuccess) e = upload(&s->dLeafIds, F.leafIds.data(), F.leafIds.size() * 4);
+    if (e == hipSuccess) e = upload(&s->dTriNormals, F.shadeRecs.data(), F.shadeRecs.size() * 4);
     if (e == hipSuccess) e = upload(&s->dMaterials, mats.data(), matBytes);
     if (e == hipSuccess) e = hipMalloc(&dCounts, 4096);
     s->ws.counts = static_cast<uint32_t*>(dCounts);
     if (e == hipSuccess) e = hipMalloc(&dCounters, 1024);
     s->ws.counters = static_cast<Counters*>(dCounters);
     if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_scene_create: upload failed: ") + hipGetErrorString(e));
-    s->dev.nodes = static_cast<const float4*>(s->dNodes) + 2 * nodes.size();         // the leaf bounds lie in front of it
+    s->dev.nodes = static_cast<const float4*>(s->dNodes) + 3 * static_cast<size_t>(F.frontSlots);     // the leaf bounds lie in front of it
     s->dev.leafTris = static_cast<const float4*>(s->dLeafTris);
     s->dev.leafIds = static_cast<const uint4*>(s->dLeafIds);
     s->dev.shadeRecs = static_cast<const float4*>(s->dTriNormals);
     s->dev.materials = static_cast<const float4*>(s->dMaterials);
-    s->dev.boxAbsMax = 0.0f;
-    for (int k = 0; k < 3; ++k) { s->dev.rootLo[k] = nodes[0].lo[k]; s->dev.rootHi[k] = nodes[0].hi[k]; }
-    for (int k = 0; k < 3; ++k)
-        s->dev.boxAbsMax = std::max(s->dev.boxAbsMax, std::max(std::fabs(nodes[0].lo[k]), std::fabs(nodes[0].hi[k])));
-    s->nodeCount = static_cast<uint32_t>(nodes.size());
-    s->leafTriCount = refCount;
-    s->depth = maxDepth;
+    s->dev.boxAbsMax = F.boxAbsMax;
+    for (int k = 0; k < 3; ++k) { s->dev.rootLo[k] = F.rootLo[k]; s->dev.rootHi[k] = F.rootHi[k]; }
+    s->nodeCount = F.nodeSlots;
+    s->leafTriCount = F.refCount;
+    s->depth = F.depth;
     s->modelCount = D->model_count;
     s->pretriCount = D->pretri_count;
     s->gridTrace[0][0] = residentBlocks(s, k_trace<false, false>, false);
@@ -2104,7 +1872,7 @@ int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, ui
                                || (D->base_tri_count && !D->base_tris)))
             return fail(RT_ERR_INVALID, "rt_scene_attach_bvh4: null array in description");
         std::vector<float> triNormals;
-        int const rcn = gatherTriNormals(D, "rt_scene_attach_bvh4", triNormals);
+        int const rcn = rt_internal_gather_tri_normals(D, "rt_scene_attach_bvh4", triNormals);
         if (rcn != RT_OK) return rcn;
         std::vector<uint8_t> used(std::max<uint32_t>(triCount, 1), 0);
         uint32_t model = 0;
@@ -2121,7 +1889,7 @@ int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, ui
             uint32_t const m = modelOf[g];
             uint32_t const rec[4] = {m, g - D->model_pretri_begin[m], g, 0u};
             std::memcpy(ids.data() + 4 * static_cast<size_t>(k), rec, 16);
-            shadeRecord(shadeRecs.data() + 12 * static_cast<size_t>(k), m, triNormals.data() + 9 * static_cast<size_t>(g));
+            rt_internal_shade_record(shadeRecs.data() + 12 * static_cast<size_t>(k), m, triNormals.data() + 9 * static_cast<size_t>(g));
         }
     }
     // ---- upload ---------------------------------------------------------------------------------------------

@@ -69,6 +69,41 @@ def serialize_scene(ray_trace_data):
     return blob
 
 
+class FlatTree:
+    """rt_debug_flatten: the node and leaf bounds records exactly as rt_scene_create uploads them (host only, no GPU).
+    `nodes` is a structured view of the node records, `bounds` of the leaf bounds records, both indexed by node slot."""
+
+    NODE_DTYPE = np.dtype([("lo", np.float32, 3), ("hi", np.float32, 3), ("index", np.int32), ("aux", np.uint32)])
+    BOUNDS_DTYPE = np.dtype([("lo", np.float32, 3), ("hi", np.float32, 3), ("cone", np.uint32), ("index", np.int32),
+                             ("cK", np.float32), ("cE", np.float32), ("pad_", np.float32, 2)])
+
+    def __init__(self, ray_trace_data):
+        L = _lib.lib()
+        desc, keep = _describe(ray_trace_data)
+        n, slots, front, amax = c_u64(0), c_u32(0), c_u32(0), c_f32(0)
+        _lib.check(L.rt_debug_flatten(ctypes.byref(desc), None, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(front),
+                                      ctypes.byref(amax)))
+        self.packed = np.zeros(n.value, np.float32)
+        _lib.check(L.rt_debug_flatten(ctypes.byref(desc), ptr(self.packed), ctypes.byref(n), ctypes.byref(slots),
+                                      ctypes.byref(front), ctypes.byref(amax)))
+        del keep
+        self.node_slots, self.front_slots, self.box_abs_max = slots.value, front.value, float(amax.value)
+        self.nodes = self.packed[12 * self.front_slots:].view(self.NODE_DTYPE)
+        self.bounds = self.packed[:12 * self.front_slots].view(self.BOUNDS_DTYPE)[::-1][:self.node_slots]
+        self.leaf_slots = np.nonzero(self.nodes["index"] < 0)[0].astype(np.uint32)
+
+    def leaf_drop(self, slots, origins, directions):
+        """rt_debug_leaf_drop: would the traversal leave the leaf at node slot slots[i] unscanned for line i?"""
+        sl = np.ascontiguousarray(slots, np.uint32)
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        assert len(sl) == len(o) == len(d)
+        out = np.zeros(len(o), np.uint8)
+        _lib.check(_lib.lib().rt_debug_leaf_drop(ptr(self.packed), c_u32(self.front_slots), c_f32(self.box_abs_max), ptr(sl),
+                                                 ptr(o), ptr(d), c_u64(len(o)), ptr(out)))
+        return out.astype(bool)
+
+
 class Bvh4:
     """rt_bvh4_build: the alternative accelerator, a 4-wide bounding volume hierarchy over preprocessed
     triangles (12 floats each), built on the host.  `nodes` (BVH4_NODE_DTYPE) and `tri_order` are copies."""
