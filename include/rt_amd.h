@@ -210,6 +210,14 @@ int rt_intersect(rt_scene* scene, const float* origins, const float* directions,
 int rt_intersect_device(rt_scene* scene, const float* d_origins, const float* d_directions, uint64_t n,
                         float t_min, int front_only, rt_hit* d_out, void* hip_stream);
 
+/* rt_intersect on the BSP tree through the kernels that count work (as RT_FLAG_COUNT_WORK does for a render): same
+ * hits, and stats receives box_tests, tris_tested, leaf_visits, inode_visits, box_exact_fallbacks and
+ * box_filter_errors -- the number of decisions of the traversal's conservative shortcuts (slab filter, leaf normal
+ * cones, leaf triangle bounds) that disagreed with the reference's exact evaluation on these lines; anything but 0 is
+ * a bug.  A test hook: the counting kernels visit every node and triangle the reference does, and are slower. */
+int rt_intersect_check(rt_scene* scene, const float* origins, const float* directions, uint64_t n, float t_min,
+                       int front_only, rt_hit* out, rt_stats* stats);
+
 /* render() (src/render.hpp:215-234): mean radiance per pixel, linear HDR, row-major, 3 floats per
  * pixel.  rt_render writes to host memory, rt_render_device to device memory (no PCIe copy). */
 int rt_render(rt_scene* scene, const rt_render_params* params, float* out_rgb, rt_stats* stats);
@@ -246,14 +254,16 @@ int rt_selftest_math(int op, const float* a, const float* b, uint32_t n, float* 
 
 /* Test hooks for the leaf triangle bounds (host only, no GPU; no counterpart in the reference, which scans every leaf
  * its line enters, src/bsp.hpp:106-117).  rt_debug_flatten returns the node and leaf bounds records exactly as
- * rt_scene_create uploads them: 12 floats per bounds record (the record of node slot s at float offset
- * 12 * (front_slots - 1 - s): lo[3], hi[3], cone word, leaf index, cK, cE, 0, 0), then 8 floats per node record (slot
- * s at 12 * front_slots + 8 * s: lo[3], hi[3], index, aux).  With packed == NULL only the sizes are returned.
+ * rt_scene_create uploads them: first the bounds records, 16 floats each (the record of node slot s at float offset
+ * 16 * (node_slots - 1 - s): lo[3], hi[3], cone word, leaf index, cK, cE, cN and five words describing the normals:
+ * sin b, cos b, A[3] when *leaf_axes is 1, ten 16-bit halves -- sin b2 and three axes -- when it is 3), then 8 floats
+ * per node record (slot s at 16 * node_slots + 8 * s: lo[3], hi[3], index, aux).  With packed == NULL only the sizes
+ * are returned.
  * rt_debug_leaf_drop evaluates, on the host and with the kernels' own arithmetic, whether the traversal would leave
  * the leaf at node slot slots[i] unscanned for line i (1) or scan it (0). */
 int rt_debug_flatten(const rt_scene_desc* desc, float* packed, uint64_t* packed_floats, uint32_t* node_slots,
-                     uint32_t* front_slots, float* box_abs_max);
-int rt_debug_leaf_drop(const float* packed, uint32_t front_slots, float box_abs_max, const uint32_t* slots,
+                     uint32_t* leaf_axes, float* box_abs_max);
+int rt_debug_leaf_drop(const float* packed, uint32_t node_slots, uint32_t leaf_axes, float box_abs_max, const uint32_t* slots,
                        const float* origins, const float* directions, uint64_t n, uint8_t* out_drop);
 
 const char* rt_last_error(void);

@@ -243,29 +243,35 @@ __device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
 // finite".  Kernels that count work scan every leaf and count an accepted hit in a leaf the rule would have dropped
 // as an error (rt_stats.box_filter_errors).
 //
-// The record of slot s sits at nodes[-3 (s + 1)] (48 bytes, {lo.xyz, hi.x} {hi.yz, cone word, index} {cK, cE, -, -}): the
+// The record of slot s sits 64 (s + 1) bytes in front of nodes[0] ({lo.xyz, hi.x} {hi.yz, cone word, index} {cK, cE, cN, n0}
+// {n1..n4}, the n words describing the normals): the
 // bounds are stored in front of the node array, mirrored, so that the kernel needs no second base address.  That matters:
 // the traversal kernel for deep trees sits at 80 scalar registers, and with two more its time on a 0.9 M-triangle scene
 // goes from 32 to 42 ms whatever the extra registers are used for.
 // The record carries copies of the leaf's cone word and index (its first triangle), which are handed out: a leaf that
 // is kept is scanned from this record alone.  WITH_CONE: the leaf's normal cone (coneAllBackFacing) is tested in the
 // same breath.
-template <bool WITH_CONE>
+// AXES: the form of the scene's bounds records, RT_LEAF_AXES_ONE (one cone) or RT_LEAF_AXES_PACKED (up to three axes; scenes
+// with leaves that hold several flat faces).
+template <bool WITH_CONE, int AXES>
 __device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r, bool rayOk, uint32_t& coneWord, int& leafIndex) {
-    const float4* bp = nodes - 3 * (static_cast<size_t>(slot) + 1);
-    float4 const b0 = bp[0], b1 = bp[1];
-    float2 const b2 = *reinterpret_cast<const float2*>(bp + 2);
+    const float4* bp = nodes - 4 * (static_cast<size_t>(slot) + 1);
+    float4 const b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
     coneWord = __float_as_uint(b1.z);
     leafIndex = __float_as_int(b1.w);
-    bool miss = rtLeafBoundsMiss(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, __float_as_uint(b1.z), b2.x, b2.y, o.x, o.y, o.z, d.x, d.y, d.z,
-                                 r.x, r.y, r.z, rayOk);
+    float const dd = __fmaf_rn(d.x, d.x, __fmaf_rn(d.y, d.y, d.z * d.z));
+    float const dlen = sqrtf(dd);
+    float const gN = AXES == RT_LEAF_AXES_ONE ? rtLeafGCone(b2.w, b3.x, b3.y, b3.z, b3.w, d.x, d.y, d.z, dd)
+                                              : rtLeafGPacked(__float_as_uint(b2.w), __float_as_uint(b3.x), __float_as_uint(b3.y),
+                                                              __float_as_uint(b3.z), __float_as_uint(b3.w), d.x, d.y, d.z, dlen);
+    bool miss = rtLeafBoundsMiss(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b2.x, b2.y, b2.z, gN, dlen, o.x, o.y, o.z, r.x, r.y, r.z, rayOk);
     if (WITH_CONE) miss = miss || coneAllBackFacing(__float_as_uint(b1.z), d);
     return miss;
 }
-template <bool WITH_CONE>
+template <bool WITH_CONE, int AXES>
 __device__ __forceinline__ bool missesLeafBounds(const float4* __restrict__ nodes, uint32_t slot, V3 o, V3 d, V3 r, bool rayOk) {
     uint32_t coneWord; int leafIndex;
-    return missesLeafBounds<WITH_CONE>(nodes, slot, o, d, r, rayOk, coneWord, leafIndex);
+    return missesLeafBounds<WITH_CONE, AXES>(nodes, slot, o, d, r, rayOk, coneWord, leafIndex);
 }
 
 // Diagnostic build only (-DRT_DIAG, make diag): per-phase cycle and lane-occupancy tallies of traceStream.
@@ -317,7 +323,10 @@ struct HitRec {
 // of every CU then runs after the others and the launch takes 30 % longer (32.1 -> 42.0 ms on a 0.9 M-triangle scene
 // for two scalar registers more).  Hence the cap, under which the compiler spills to vector lanes instead.
 #define RT_PERSISTENT_SGPRS __attribute__((amdgpu_num_sgpr(82)))          // reported as "TotalSGPRs: 80"
-template <bool FRONT_ONLY, bool COUNT, bool SPILL, class Load, class Store>
+// The BSP traversal kernels are also held to 64 vector registers, i.e. eight waves per SIMD (the compiler reorders the
+// leaf bounds test to fit instead of taking 66 and seven waves; nothing is spilt in the kernels that render).
+#define RT_EIGHT_WAVES __attribute__((amdgpu_waves_per_eu(8, 8)))
+template <bool FRONT_ONLY, bool COUNT, bool SPILL, int AXES, class Load, class Store>
 __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint32_t* __restrict__ nextLine, float tMin,
                                             Counters& c, Load load, Store store) {
     constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -496,16 +505,16 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             // before a candidate hit is checked against the leaf's box: a lane's last test is the one of the leaf it keeps
             // (a test runs whenever some lane dropped a leaf, and a lane that dropped none repeats its own).
             uint32_t word = 0; int leafIndex = -1;
-            bool drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
+            bool drop = missesLeafBounds<FRONT_ONLY && SPILL, AXES>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
             pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
             if (__ballot(drop) != 0ull) {
-                drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
+                drop = missesLeafBounds<FRONT_ONLY && SPILL, AXES>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
                 pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                 if (__ballot(drop) != 0ull) {
-                    drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
+                    drop = missesLeafBounds<FRONT_ONLY && SPILL, AXES>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
                     pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                     if (__ballot(drop) != 0ull) {
-                        drop = missesLeafBounds<FRONT_ONLY && SPILL>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
+                        drop = missesLeafBounds<FRONT_ONLY && SPILL, AXES>(S.nodes, pend1 != NONE ? pend1 : 0u, o, d, r, mu < INFINITY, word, leafIndex) && pend1 != NONE;
                         pend1 = drop ? pend2 : pend1; pend2 = drop ? pend3 : pend2; pend3 = drop ? pend4 : pend3; pend4 = drop ? NONE : pend4;
                     }
                 }
@@ -524,7 +533,7 @@ __device__ __forceinline__ void traceStream(const DevScene& S, uint32_t n, uint3
             leafFirst = static_cast<uint32_t>(-(__float_as_int(q1.z) + 1));
             leafCount = leafTriCount(__float_as_uint(q1.w));
             coneSkips = COUNT && FRONT_ONLY && coneAllBackFacing(__float_as_uint(q1.w), d);
-            boundsSkip = COUNT && missesLeafBounds<false>(S.nodes, pend1, o, d, r, mu < INFINITY);
+            boundsSkip = COUNT && missesLeafBounds<false, AXES>(S.nodes, pend1, o, d, r, mu < INFINITY);
             pend1 = pend2; pend2 = pend3; pend3 = pend4; pend4 = NONE;
         }
 
@@ -1057,14 +1066,15 @@ __device__ __forceinline__ void flushCounters(const Counters& c, Counters* g) {
     }
 }
 
-// rt_intersect: one lane per line.
-template <bool FRONT_ONLY, bool SPILL>
-__global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS void k_intersect(DevScene S, const float* __restrict__ origins,
+// rt_intersect: one lane per line.  COUNT (rt_intersect_check): the traversal that counts work and cross-checks every
+// conservative shortcut against the exact evaluation, as k_trace<true, .> does for a render.
+template <bool FRONT_ONLY, bool SPILL, bool COUNT, int AXES>
+__global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS RT_EIGHT_WAVES void k_intersect(DevScene S, const float* __restrict__ origins,
                                                         const float* __restrict__ directions, uint32_t n,
                                                         float tMin, rt_hit* __restrict__ out,
-                                                        uint32_t* __restrict__ nextLine) {
+                                                        uint32_t* __restrict__ nextLine, Counters* __restrict__ gc) {
     Counters c = {};
-    traceStream<FRONT_ONLY, false, SPILL>(
+    traceStream<FRONT_ONLY, COUNT, SPILL, AXES>(
         S, n, nextLine, tMin, c,
         [&](uint32_t i, V3& o, V3& d) {
             o = mk(origins[3 * static_cast<size_t>(i)], origins[3 * static_cast<size_t>(i) + 1], origins[3 * static_cast<size_t>(i) + 2]);
@@ -1085,6 +1095,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS void k_intersect(DevS
             }
             out[i] = r;
         });
+    if (COUNT) flushCounters(c, gc);
 }
 
 template <bool FRONT_ONLY, bool SPILL, bool MERGED>
@@ -1209,13 +1220,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderConst R, PathState P,
 // One closest-hit query per live path.  `bounce` selects the input queue; bounce 0 is the identity.
 // counts[RT_FETCH_BASE + bounce] is this launch's line-fetch cursor (zeroed with the counts).
 #define RT_FETCH_BASE 512u
-template <bool COUNT, bool SPILL>
-__global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS void k_trace(DevScene S, PathState P, uint32_t bounce, float tMin,
+template <bool COUNT, bool SPILL, int AXES>
+__global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS RT_EIGHT_WAVES void k_trace(DevScene S, PathState P, uint32_t bounce, float tMin,
                                                     Counters* __restrict__ gc) {
     uint32_t const n = P.counts[bounce];
     uint32_t const* __restrict__ q = P.queue[bounce & 1];
     Counters c = {};
-    traceStream<true, COUNT, SPILL>(
+    traceStream<true, COUNT, SPILL, AXES>(
         S, n, P.counts + RT_FETCH_BASE + bounce, tMin, c,
         [&](uint32_t i, V3& o, V3& d) {
             uint32_t const slot = bounce == 0 ? i : q[i];
@@ -1596,6 +1607,7 @@ struct rt_scene {
     // that no later call has to query or allocate.
     int gridTrace[2][2] = {{0, 0}, {0, 0}};
     int gridIntersect[2][2] = {{0, 0}, {0, 0}};
+    bool leafAxesMany = false;          // form of the leaf bounds records (rt_leaf_bounds.h): selects the kernel variant
     // Blocks of k_shade per CU: no more than are resident at once (a grid of 8 per CU against 6 resident left a tail at a
     // third of the occupancy: 2.46 -> 2.32 ms per 16 spp on the 0.9 M-triangle scene), and 5 measure a little better still.
     int shadeBlocksPerCu = 5;
@@ -1784,7 +1796,7 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     if (e == hipSuccess) e = hipMalloc(&dCounters, 1024);
     s->ws.counters = static_cast<Counters*>(dCounters);
     if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_scene_create: upload failed: ") + hipGetErrorString(e));
-    s->dev.nodes = static_cast<const float4*>(s->dNodes) + 3 * static_cast<size_t>(F.frontSlots);     // the leaf bounds lie in front of it
+    s->dev.nodes = static_cast<const float4*>(s->dNodes) + 4 * static_cast<size_t>(F.frontSlots);     // the leaf bounds lie in front of it
     s->dev.leafTris = static_cast<const float4*>(s->dLeafTris);
     s->dev.leafIds = static_cast<const uint4*>(s->dLeafIds);
     s->dev.shadeRecs = static_cast<const float4*>(s->dTriNormals);
@@ -1796,14 +1808,20 @@ int sceneCreate(const rt_scene_desc* D, int device, rt_scene** out) {
     s->depth = F.depth;
     s->modelCount = D->model_count;
     s->pretriCount = D->pretri_count;
-    s->gridTrace[0][0] = residentBlocks(s, k_trace<false, false>, false);
-    s->gridTrace[0][1] = residentBlocks(s, k_trace<false, true>, true);
-    s->gridTrace[1][0] = residentBlocks(s, k_trace<true, false>, false);
-    s->gridTrace[1][1] = residentBlocks(s, k_trace<true, true>, true);
-    s->gridIntersect[0][0] = residentBlocks(s, k_intersect<false, false>, false);
-    s->gridIntersect[0][1] = residentBlocks(s, k_intersect<false, true>, true);
-    s->gridIntersect[1][0] = residentBlocks(s, k_intersect<true, false>, false);
-    s->gridIntersect[1][1] = residentBlocks(s, k_intersect<true, true>, true);
+    s->leafAxesMany = F.leafAxes == RT_LEAF_AXES_PACKED;
+#define RT_GRIDS(AXES)                                                                                     \
+    do {                                                                                                   \
+        s->gridTrace[0][0] = residentBlocks(s, k_trace<false, false, AXES>, false);                        \
+        s->gridTrace[0][1] = residentBlocks(s, k_trace<false, true, AXES>, true);                          \
+        s->gridTrace[1][0] = residentBlocks(s, k_trace<true, false, AXES>, false);                         \
+        s->gridTrace[1][1] = residentBlocks(s, k_trace<true, true, AXES>, true);                           \
+        s->gridIntersect[0][0] = residentBlocks(s, k_intersect<false, false, false, AXES>, false);         \
+        s->gridIntersect[0][1] = residentBlocks(s, k_intersect<false, true, false, AXES>, true);           \
+        s->gridIntersect[1][0] = residentBlocks(s, k_intersect<true, false, false, AXES>, false);          \
+        s->gridIntersect[1][1] = residentBlocks(s, k_intersect<true, true, false, AXES>, true);            \
+    } while (0)
+    if (s->leafAxesMany) RT_GRIDS(RT_LEAF_AXES_PACKED); else RT_GRIDS(RT_LEAF_AXES_ONE);
+#undef RT_GRIDS
     {
         int perCu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_shade, RT_BLOCK, 0) == hipSuccess && perCu > 0) s->shadeBlocksPerCu = std::min(perCu, 5);
@@ -2031,8 +2049,13 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
                 if (s->bvhMerged) RT_LAUNCH_TRACE_BVH(true); else RT_LAUNCH_TRACE_BVH(false);
             }
             else {
-                if (countWork) { if (spill) RT_LAUNCH_TRACE(k_trace, true, true); else RT_LAUNCH_TRACE(k_trace, true, false); }
-                else { if (spill) RT_LAUNCH_TRACE(k_trace, false, true); else RT_LAUNCH_TRACE(k_trace, false, false); }
+#define RT_LAUNCH_TRACE_BSP(AXES)                                                                              \
+    do {                                                                                                       \
+        if (countWork) { if (spill) RT_LAUNCH_TRACE(k_trace, true, true, AXES); else RT_LAUNCH_TRACE(k_trace, true, false, AXES); }     \
+        else { if (spill) RT_LAUNCH_TRACE(k_trace, false, true, AXES); else RT_LAUNCH_TRACE(k_trace, false, false, AXES); }             \
+    } while (0)
+                if (s->leafAxesMany) RT_LAUNCH_TRACE_BSP(RT_LEAF_AXES_PACKED); else RT_LAUNCH_TRACE_BSP(RT_LEAF_AXES_ONE);
+#undef RT_LAUNCH_TRACE_BSP
             }
 #undef RT_LAUNCH_TRACE_BVH
 #undef RT_LAUNCH_TRACE
@@ -2188,6 +2211,9 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
 #define RT_LAUNCH_INTERSECT(KERNEL, ...)                                                                      \
     hipLaunchKernelGGL((KERNEL<__VA_ARGS__>), dim3(persistentGrid(cap, m)), dim3(RT_BLOCK), 0, st, dev,        \
                        d_origins + 3 * done, d_directions + 3 * done, m, t_min, d_out + done, cursor)
+#define RT_LAUNCH_INTERSECT_GC(KERNEL, ...)                                                                   \
+    hipLaunchKernelGGL((KERNEL<__VA_ARGS__>), dim3(persistentGrid(cap, m)), dim3(RT_BLOCK), 0, st, dev,        \
+                       d_origins + 3 * done, d_directions + 3 * done, m, t_min, d_out + done, cursor, static_cast<Counters*>(nullptr))
 #define RT_LAUNCH_INTERSECT_BVH(MERGED)                                                                        \
     do {                                                                                                       \
         if (front) { if (spill) RT_LAUNCH_INTERSECT(k_intersect_bvh, true, true, MERGED); else RT_LAUNCH_INTERSECT(k_intersect_bvh, true, false, MERGED); }     \
@@ -2197,20 +2223,31 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
             if (s->bvhMerged) RT_LAUNCH_INTERSECT_BVH(true); else RT_LAUNCH_INTERSECT_BVH(false);
         }
         else {
-            if (front) { if (spill) RT_LAUNCH_INTERSECT(k_intersect, true, true); else RT_LAUNCH_INTERSECT(k_intersect, true, false); }
-            else { if (spill) RT_LAUNCH_INTERSECT(k_intersect, false, true); else RT_LAUNCH_INTERSECT(k_intersect, false, false); }
+#define RT_LAUNCH_INTERSECT_BSP(AXES)                                                                          \
+    do {                                                                                                       \
+        if (front) { if (spill) RT_LAUNCH_INTERSECT_GC(k_intersect, true, true, false, AXES); else RT_LAUNCH_INTERSECT_GC(k_intersect, true, false, false, AXES); }     \
+        else { if (spill) RT_LAUNCH_INTERSECT_GC(k_intersect, false, true, false, AXES); else RT_LAUNCH_INTERSECT_GC(k_intersect, false, false, false, AXES); }         \
+    } while (0)
+            if (s->leafAxesMany) RT_LAUNCH_INTERSECT_BSP(RT_LEAF_AXES_PACKED); else RT_LAUNCH_INTERSECT_BSP(RT_LEAF_AXES_ONE);
+#undef RT_LAUNCH_INTERSECT_BSP
         }
 #undef RT_LAUNCH_INTERSECT_BVH
+#undef RT_LAUNCH_INTERSECT_GC
 #undef RT_LAUNCH_INTERSECT
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
 
-int rt_intersect(rt_scene* s, const float* origins, const float* directions, uint64_t n, float t_min, int front_only,
-                 rt_hit* out) {
+namespace {
+// Host-pointer form shared by rt_intersect and rt_intersect_check (stats != nullptr: the counting traversal of the BSP tree).
+int intersectHost(rt_scene* s, const float* origins, const float* directions, uint64_t n, float t_min, int front_only,
+                  rt_hit* out, rt_stats* stats) {
     if (!s || (n && (!origins || !directions || !out))) return fail(RT_ERR_INVALID, "rt_intersect: null argument");
+    if (stats) std::memset(stats, 0, sizeof *stats);
     if (n == 0) return RT_OK;
+    if (stats && (front_only & RT_INTERSECT_BVH)) return fail(RT_ERR_INVALID, "rt_intersect_check: the BSP tree only");
+    if (stats && n > 0xF0000000ull) return fail(RT_ERR_LIMIT, "rt_intersect_check: too many lines");
     HIP_TRY(hipSetDevice(s->device));
     float *dO = nullptr, *dD = nullptr;
     rt_hit* dH = nullptr;
@@ -2220,17 +2257,60 @@ int rt_intersect(rt_scene* s, const float* origins, const float* directions, uin
     if (e == hipSuccess) e = hipMalloc(&dH, n * sizeof(rt_hit));
     if (e == hipSuccess) e = hipMemcpy(dO, origins, n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dD, directions, n * 12, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
+    if (e == hipSuccess && !stats) {
         rc = rt_intersect_device(s, dO, dD, n, t_min, front_only, dH, nullptr);
         if (rc == RT_OK) e = hipDeviceSynchronize();
-        if (rc == RT_OK && e == hipSuccess) e = hipMemcpy(out, dH, n * sizeof(rt_hit), hipMemcpyDeviceToHost);
     }
+    else if (e == hipSuccess) {
+        if (s->hasLastStream) e = hipStreamSynchronize(s->lastStream);
+        Counters* gc = s->ws.counters;
+        uint32_t* cursor = reinterpret_cast<uint32_t*>(gc) + 64;     // behind the Counters block
+        if (e == hipSuccess) e = hipMemset(gc, 0, 512);      // the counters and the cursor
+        bool const front = (front_only & RT_INTERSECT_FRONT_ONLY) != 0, spill = s->depth > RT_LDS_STACK_DEPTH;
+        uint32_t const m = static_cast<uint32_t>(n);
+#define RT_LAUNCH_CHECK(F, S, AXES)                                                                                  \
+    hipLaunchKernelGGL((k_intersect<F, S, true, AXES>), dim3(persistentGrid(residentBlocks(s, k_intersect<F, S, true, AXES>, S), m)), \
+                       dim3(RT_BLOCK), 0, nullptr, s->dev, dO, dD, m, t_min, dH, cursor, gc)
+#define RT_LAUNCH_CHECK_BSP(AXES)                                                                                    \
+    do {                                                                                                             \
+        if (front) { if (spill) RT_LAUNCH_CHECK(true, true, AXES); else RT_LAUNCH_CHECK(true, false, AXES); }        \
+        else { if (spill) RT_LAUNCH_CHECK(false, true, AXES); else RT_LAUNCH_CHECK(false, false, AXES); }            \
+    } while (0)
+        if (e == hipSuccess) {
+            if (s->leafAxesMany) RT_LAUNCH_CHECK_BSP(RT_LEAF_AXES_PACKED); else RT_LAUNCH_CHECK_BSP(RT_LEAF_AXES_ONE);
+            e = hipGetLastError();
+        }
+#undef RT_LAUNCH_CHECK_BSP
+#undef RT_LAUNCH_CHECK
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        Counters hc;
+        if (e == hipSuccess) e = hipMemcpy(&hc, gc, sizeof hc, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            stats->segments = n;
+            stats->box_tests = hc.boxTests; stats->tris_tested = hc.trisTested; stats->leaf_visits = hc.leafVisits;
+            stats->inode_visits = hc.inodeVisits;
+            stats->box_exact_fallbacks = hc.boxFallbacks; stats->box_filter_errors = hc.boxFilterErrors;
+        }
+    }
+    if (rc == RT_OK && e == hipSuccess) e = hipMemcpy(out, dH, n * sizeof(rt_hit), hipMemcpyDeviceToHost);
     if (dO) (void)hipFree(dO);
     if (dD) (void)hipFree(dD);
     if (dH) (void)hipFree(dH);
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_intersect: ") + hipGetErrorString(e));
     return RT_OK;
+}
+}  // namespace
+
+int rt_intersect(rt_scene* s, const float* origins, const float* directions, uint64_t n, float t_min, int front_only,
+                 rt_hit* out) {
+    return guarded("rt_intersect", [&] { return intersectHost(s, origins, directions, n, t_min, front_only, out, nullptr); });
+}
+
+int rt_intersect_check(rt_scene* s, const float* origins, const float* directions, uint64_t n, float t_min, int front_only,
+                       rt_hit* out, rt_stats* stats) {
+    if (!stats) return fail(RT_ERR_INVALID, "rt_intersect_check: null stats");
+    return guarded("rt_intersect_check", [&] { return intersectHost(s, origins, directions, n, t_min, front_only, out, stats); });
 }
 
 int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* stats, void* hip_stream) {

@@ -5,6 +5,7 @@
 #include "rt_leaf_bounds.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,9 +19,21 @@ int fail(int code, const std::string& msg) { return rt_internal_fail(code, msg.c
 // Node record as the kernels read it, 32 bytes: {lo.xyz, hi.x} {hi.yz, index, aux}.
 struct HNode { float lo[3], hi[3]; int32_t index; uint32_t aux; };
 static_assert(sizeof(HNode) == 32, "node record must be 32 bytes");
-// Leaf bounds record, 48 bytes: {lo.xyz, hi.x} {hi.yz, cone word, leaf index} {cK, cE, 0, 0} (rt_leaf_bounds.h).
-struct BRec { float lo[3], hi[3]; uint32_t cone; int32_t index; float cK, cE, pad0, pad1; };
-static_assert(sizeof(BRec) == 48, "bounds record must be 48 bytes");
+// Leaf bounds record (rt_leaf_bounds.h), 64 bytes: {lo.xyz, hi.x} {hi.yz, cone word, leaf index} {cK, cE, cN, n0} {n1 .. n4}
+// with the normals' description in n0..n4: {sin b, cos b, A1.xyz} as floats (cone form) or ten 16-bit halves (axes form).
+struct BRec { float lo[3], hi[3]; uint32_t cone; int32_t index; float cK, cE, cN; uint32_t n[5]; };
+static_assert(sizeof(BRec) == 64, "bounds record must be 64 bytes");
+// What leafBounds works out for a leaf, before it is laid out for one of the two record forms.
+struct LeafDescription {
+    BRec base{};                          // box, words and coefficients; the normals' fields are filled by layOut
+    bool finite = false;
+    int axisCount = 0;                    // 0: no axes form; else the axes form with this many axes
+    float axes[RT_LEAF_AXES_PACKED][3] = {};
+    double axesSpread = 4.0;
+    bool hasCone = false;                 // one cone around all normals
+    float coneAxis[3] = {0, 0, 0};
+    double coneSpread = 4.0;
+};
 
 // Cone code of a leaf (bits 8-30 of the leaf record's aux word; 0: none), from the normals that head the leaf's triangle
 // records (12 floats each).  The axis is the integer point nearest to 31 times the mean unit normal; the threshold is
@@ -73,17 +86,38 @@ float roundedDown(double x) {
     return f;
 }
 
-// The bounds record of one leaf (rt_leaf_bounds.h): the box around the triangles as the triangle test sees them (v1,
-// v1 + v1ToV2, v1 + v1ToV3), cut to the leaf's box and padded by 2^-22 of the largest box coordinate, and the two
-// coefficients of the widening, from the longest first-corner edge and the flattest first corner among the triangles.
+// Largest angle between a unit vector of `units` and the nearest of +-axes[0..count) (axes as stored, any length).
+double spreadAbout(const std::vector<std::array<double, 3>>& units, const float (*axes)[3], int count) {
+    double spread = 0.0;
+    for (auto const& u : units) {
+        double best = -1.0;
+        for (int a = 0; a < count; ++a) {
+            double const len = std::sqrt(double(axes[a][0]) * axes[a][0] + double(axes[a][1]) * axes[a][1] + double(axes[a][2]) * axes[a][2]);
+            if (!(len > 0.0)) continue;
+            best = std::max(best, std::fabs(u[0] * axes[a][0] + u[1] * axes[a][1] + u[2] * axes[a][2]) / len);
+        }
+        if (best < 0.0) return 4.0;
+        spread = std::max(spread, std::acos(std::min(1.0, best)));
+    }
+    return spread;
+}
+
+// What the bounds record of one leaf is made from (rt_leaf_bounds.h): the box around the triangles as the triangle test
+// sees them (v1, v1 + v1ToV2, v1 + v1ToV3), cut to the leaf's box and padded by 2^-22 of the largest box coordinate; the
+// coefficients of the widening, from the longest first-corner edge, the flattest first corner and the longest normal
+// among the triangles; and two descriptions of the normals: axes found greedily (a normal joins the axis it lies
+// within 0.12 rad of, up to sign, else founds a new one; at most three), refined to the mean of their members,
+// and one cone around the mean of all normals (signs folded onto the first).
 // `unbounded` (measurements): bounds no line misses.
-BRec leafBounds(const HNode& node, const float* records, uint32_t count, double absMax, bool unbounded) {
-    BRec out{};
+LeafDescription describeLeaf(const HNode& node, const float* records, uint32_t count, double absMax, bool unbounded) {
+    LeafDescription L;
+    BRec& out = L.base;
     out.cone = node.aux;                  // the leaf's cone word and triangle index: the kernels start the scan from
     out.index = node.index;               // this record alone
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool finite = !unbounded && absMax >= 0x1p-60 && absMax <= 0x1p100;
-    double eMax = 0.0, kappaMax = 0.0;
+    double eMax = 0.0, kappaMax = 0.0, nMax = 0.0;
+    std::vector<std::array<double, 3>> units;
     for (uint32_t i = 0; i < count; ++i) {
         float const* rec = records + 12 * static_cast<size_t>(i);       // normal, v1, v1ToV3, v1ToV2
         double e13 = 0.0, e12 = 0.0, nn = 0.0;
@@ -97,14 +131,31 @@ BRec leafBounds(const HNode& node, const float* records, uint32_t count, double 
             nn += double(rec[k]) * rec[k];
         }
         if (nn == 0.0) continue;            // a zero normal never passes the facing test (its determinant is an exact zero)
+        // The rule's proof takes the stored normal for the rounded cross product of the stored edges (either order), as
+        // preprocessTri makes it (src/geometry.hpp:77-82).  A caller's record that is anything else switches the rule off
+        // for its leaf.
+        {
+            double const a[3] = {rec[9], rec[10], rec[11]}, b[3] = {rec[6], rec[7], rec[8]};          // v1ToV2, v1ToV3
+            bool asMade = true, reversed = true;
+            for (int k = 0; k < 3; ++k) {
+                double const p = a[(k + 1) % 3] * b[(k + 2) % 3], q = a[(k + 2) % 3] * b[(k + 1) % 3];
+                double const slack = 2.0 * 0x1p-24 * (std::fabs(p) + std::fabs(q)) * (1.0 + 1e-6) + 0x1p-140;
+                asMade = asMade && std::fabs(double(rec[k]) - (p - q)) <= slack;
+                reversed = reversed && std::fabs(double(rec[k]) + (p - q)) <= slack;
+            }
+            if (!asMade && !reversed) finite = false;
+        }
         double const e2 = std::max(e13, e12);          // squared length of the longer edge
+        double const len = std::sqrt(nn);
         eMax = std::max(eMax, std::sqrt(e2));
-        kappaMax = std::max(kappaMax, e2 / std::sqrt(nn));
+        kappaMax = std::max(kappaMax, e2 / len);
+        nMax = std::max(nMax, len);
+        units.push_back({rec[0] / len, rec[1] / len, rec[2] / len});
     }
     double const eps = 0x1p-24;
     double const cK = std::sqrt(3.0) * eps * (32.0 * kappaMax + 8.0) * (1.0 + 1e-6);
     double const cE = 2.0 * eMax * cK * (1.0 + 1e-6);
-    if (!std::isfinite(cK) || !std::isfinite(cE)) finite = false;
+    if (!std::isfinite(cK) || !std::isfinite(cE) || !(nMax > 0.0)) finite = false;
     double const pad = std::ldexp(absMax, -22);
     for (int k = 0; k < 3; ++k) {
         double l = -INFINITY, h = INFINITY;              // non-finite vertices: no bounds
@@ -115,9 +166,87 @@ BRec leafBounds(const HNode& node, const float* records, uint32_t count, double 
         out.lo[k] = roundedDown(l);
         out.hi[k] = roundedUp(h);
     }
-    out.cK = finite ? roundedUp(cK) : INFINITY;
+    out.cK = finite ? roundedUp(cK) : INFINITY;           // an infinite cK switches the rule off for the leaf
     out.cE = finite ? roundedUp(cE) : INFINITY;
-    return out;
+    out.cN = finite ? roundedDown(0.999e-6 / nMax) : 0.0f;
+    L.finite = finite;
+    if (!finite || units.empty() || count >= 4096) return L;
+    // ---- the normals ----
+    double sums[RT_LEAF_AXES_PACKED][3] = {}, all[3] = {0, 0, 0};
+    int found = 0;
+    bool fits = true;
+    double const joinCos = std::cos(0.12);
+    for (auto const& u : units) {
+        int best = -1;
+        double bestDot = 0.0;
+        for (int a = 0; a < found; ++a) {
+            double const len = std::sqrt(sums[a][0] * sums[a][0] + sums[a][1] * sums[a][1] + sums[a][2] * sums[a][2]);
+            double const dot = (u[0] * sums[a][0] + u[1] * sums[a][1] + u[2] * sums[a][2]) / len;
+            if (std::fabs(dot) > std::fabs(bestDot)) { bestDot = dot; best = a; }
+        }
+        if (best >= 0 && std::fabs(bestDot) >= joinCos) {
+            double const sign = bestDot < 0.0 ? -1.0 : 1.0;
+            for (int k = 0; k < 3; ++k) sums[best][k] += sign * u[k];
+        }
+        else if (found < RT_LEAF_AXES_PACKED) { for (int k = 0; k < 3; ++k) sums[found][k] = u[k]; ++found; }
+        else fits = false;
+        double const signAll = (u[0] * units[0][0] + u[1] * units[0][1] + u[2] * units[0][2]) < 0.0 ? -1.0 : 1.0;
+        for (int k = 0; k < 3; ++k) all[k] += signAll * u[k];
+    }
+    auto store = [](float* dst, const double* v) -> bool {
+        double const len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (!(len > 1e-9)) return false;
+        for (int k = 0; k < 3; ++k) dst[k] = static_cast<float>(v[k] / len);
+        return true;
+    };
+    if (fits) {
+        bool ok = true;
+        for (int a = 0; a < found; ++a) ok = ok && store(L.axes[a], sums[a]);
+        if (ok) {
+            L.axesSpread = spreadAbout(units, L.axes, found) + 1e-6;
+            L.axisCount = found;
+            for (int a = found; a < RT_LEAF_AXES_PACKED; ++a) for (int k = 0; k < 3; ++k) L.axes[a][k] = L.axes[found - 1][k];
+        }
+    }
+    float cone[1][3];
+    if (store(cone[0], all)) {
+        L.coneSpread = spreadAbout(units, cone, 1) + 1e-6;
+        L.hasCone = L.coneSpread < 1.57;
+        for (int k = 0; k < 3; ++k) L.coneAxis[k] = cone[0][k];
+    }
+    return L;
+}
+
+// Is the leaf one of several flat faces (what the axes form is for)?  Two or three axes, every normal within 0.01 rad of
+// one of them, and no cone that narrow around all of them.
+bool prefersAxes(const LeafDescription& L) {
+    return L.axisCount >= 2 && L.axesSpread < 0.01 && !(L.hasCone && L.coneSpread < 0.02);
+}
+
+// Fills the normals' words of the record for the cone form (packed == false) or the axes form.
+BRec layOut(const LeafDescription& L, bool packed) {
+    BRec r = L.base;
+    auto sine = [](double b) { return roundedUp(std::min(1.0, std::sin(b) * (1.0 + 0x1p-18) + 0x1p-20)); };
+    auto cosine = [](double b) { return roundedDown(std::max(0.0, std::cos(b) * (1.0 - 0x1p-18))); };
+    if (!packed) {
+        float f[5] = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (L.finite && L.hasCone) { f[0] = sine(L.coneSpread); f[1] = cosine(L.coneSpread); std::memcpy(f + 2, L.coneAxis, 12); }
+        std::memcpy(r.n, f, 20);
+        return r;
+    }
+    // axes form: the leaf's own axes, or its cone's axis three times with the cone's half-angle
+    float axes[3][3] = {};
+    double spread = 4.0;
+    if (L.finite && L.axisCount >= 1 && (prefersAxes(L) || (L.axesSpread <= L.coneSpread))) { std::memcpy(axes, L.axes, sizeof axes); spread = L.axesSpread; }
+    else if (L.finite && L.hasCone) { for (auto& axis : axes) std::memcpy(axis, L.coneAxis, 12); spread = L.coneSpread; }
+    uint16_t h[10] = {};
+    double const sinB2 = spread < 1.57 ? std::sin(spread + 0x1p-14) * (1.0 + 0x1p-18) + 0x1p-20 : 1.0;
+    h[0] = static_cast<uint16_t>(std::min(65535.0, std::ceil(std::min(sinB2, 1.0) * 65536.0)));     // 65535: 2 sin b2 just below 2, no bound
+    for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < 3; ++k)
+            h[1 + 3 * a + k] = static_cast<uint16_t>(static_cast<int16_t>(std::lrint(std::max(-1.0, std::min(1.0, double(axes[a][k]))) * 32767.0)));
+    for (int w = 0; w < 5; ++w) r.n[w] = static_cast<uint32_t>(h[2 * w]) | (static_cast<uint32_t>(h[2 * w + 1]) << 16);
+    return r;
 }
 
 }  // namespace
@@ -256,23 +385,42 @@ int rt_internal_flatten(const rt_scene_desc* D, rt_flat_scene& F) {
                      leavesWithCone ? double(thresholdSum) / 31.0 / double(leavesWithCone) : 0.0);
     // ---- node records behind the leaf bounds records (layout: rt_flatten.h) -------------------------------------
     size_t const N = nodes.size();
-    size_t const front = (N + 3) & ~static_cast<size_t>(3);
-    F.nodeSlots = static_cast<uint32_t>(N);
-    F.frontSlots = static_cast<uint32_t>(front);
-    F.packed.assign(12 * front + 8 * N, 0.0f);
     double absMax = 0.0;
     for (int k = 0; k < 3; ++k) absMax = std::max(absMax, std::max(std::fabs(double(nodes[0].lo[k])), std::fabs(double(nodes[0].hi[k]))));
     // RT_AMD_LEAF_BOUNDS=0 (measurements): every leaf gets unbounded bounds, which no line misses
     bool const unbounded = std::getenv("RT_AMD_LEAF_BOUNDS") && std::atoi(std::getenv("RT_AMD_LEAF_BOUNDS")) == 0;
+    std::vector<LeafDescription> described;
+    described.reserve(leavesSeen);
+    size_t wantAxes = 0;
     for (size_t slot = 0; slot < N; ++slot) {
         HNode const& node = nodes[slot];
-        std::memcpy(F.packed.data() + 12 * front + 8 * slot, &node, 32);
         if (node.index >= 0) continue;
         uint32_t const first = static_cast<uint32_t>(-(node.index + 1));
         uint32_t const leafCount = (node.aux & 0x80000000u) ? (node.aux & 0x7FFFFFFFu) : (node.aux & 0xFFu);
-        BRec const rec = leafBounds(node, F.leafTris.data() + 12 * static_cast<size_t>(first), leafCount, absMax, unbounded);
-        std::memcpy(F.packed.data() + 12 * (front - 1 - slot), &rec, 48);
+        described.push_back(describeLeaf(node, F.leafTris.data() + 12 * static_cast<size_t>(first), leafCount, absMax, unbounded));
+        if (described.back().finite && prefersAxes(described.back())) ++wantAxes;
     }
+    // Scenes in which at least one leaf in ten holds several flat faces (boxes, rooms) get the axes form in all their
+    // records; the others (smooth surfaces) the cone form, whose angle sum is the sharper bound for a curved patch.
+    // RT_AMD_LEAF_AXES=1 / 3 forces the form (measurements).
+    bool many = wantAxes * 10 >= described.size() && wantAxes > 0;
+    if (const char* text = std::getenv("RT_AMD_LEAF_AXES")) many = std::atoi(text) > 1;
+    F.leafAxes = many ? RT_LEAF_AXES_PACKED : RT_LEAF_AXES_ONE;
+    size_t const recFloats = 16;
+    F.nodeSlots = static_cast<uint32_t>(N);
+    F.frontSlots = static_cast<uint32_t>(N);
+    F.packed.assign(recFloats * N + 8 * N, 0.0f);
+    size_t leaf = 0;
+    for (size_t slot = 0; slot < N; ++slot) {
+        HNode const& node = nodes[slot];
+        std::memcpy(F.packed.data() + recFloats * N + 8 * slot, &node, 32);
+        if (node.index >= 0) continue;
+        BRec const rec = layOut(described[leaf++], many);
+        std::memcpy(F.packed.data() + recFloats * (N - 1 - slot), &rec, 4 * recFloats);
+    }
+    if (std::getenv("RT_AMD_DEBUG"))
+        std::fprintf(stderr, "rt_amd: %zu of %zu leaves hold several flat faces: bounds records in the %s form\n",
+                     wantAxes, described.size(), many ? "axes" : "cone");
     // ---- shading records in the order of the leaf triangle records ------------------------------
     std::vector<float> triNormals;
     {
@@ -298,7 +446,7 @@ extern "C" {
 
 // Test hooks, host only (declared in rt_amd.h).
 int rt_debug_flatten(const rt_scene_desc* D, float* packed, uint64_t* packed_floats, uint32_t* node_slots,
-                     uint32_t* front_slots, float* box_abs_max) {
+                     uint32_t* leaf_axes, float* box_abs_max) {
     try {
         if (!D || !packed_floats) return fail(RT_ERR_INVALID, "rt_debug_flatten: null argument");
         rt_flat_scene F;
@@ -306,7 +454,7 @@ int rt_debug_flatten(const rt_scene_desc* D, float* packed, uint64_t* packed_flo
         if (rc != RT_OK) return rc;
         uint64_t const need = F.packed.size();
         if (node_slots) *node_slots = F.nodeSlots;
-        if (front_slots) *front_slots = F.frontSlots;
+        if (leaf_axes) *leaf_axes = F.leafAxes;
         if (box_abs_max) *box_abs_max = F.boxAbsMax;
         if (!packed) { *packed_floats = need; return RT_OK; }
         if (*packed_floats < need) { *packed_floats = need; return fail(RT_ERR_LIMIT, "rt_debug_flatten: buffer too small"); }
@@ -318,19 +466,19 @@ int rt_debug_flatten(const rt_scene_desc* D, float* packed, uint64_t* packed_flo
     catch (...) { return fail(RT_ERR_INVALID, "rt_debug_flatten: unexpected exception"); }
 }
 
-int rt_debug_leaf_drop(const float* packed, uint32_t front_slots, float box_abs_max, const uint32_t* slots,
+int rt_debug_leaf_drop(const float* packed, uint32_t node_slots, uint32_t leaf_axes, float box_abs_max, const uint32_t* slots,
                        const float* origins, const float* directions, uint64_t n, uint8_t* out_drop) {
     if (!packed || !slots || !origins || !directions || !out_drop) return fail(RT_ERR_INVALID, "rt_debug_leaf_drop: null argument");
+    if (leaf_axes != RT_LEAF_AXES_ONE && leaf_axes != RT_LEAF_AXES_PACKED) return fail(RT_ERR_INVALID, "rt_debug_leaf_drop: bad record form");
+    size_t const recFloats = 16;
     for (uint64_t i = 0; i < n; ++i) {
-        if (slots[i] >= front_slots) return fail(RT_ERR_INVALID, "rt_debug_leaf_drop: slot out of range");
-        BRec rec;
-        std::memcpy(&rec, packed + 12 * (static_cast<size_t>(front_slots) - 1 - slots[i]), 48);
+        if (slots[i] >= node_slots) return fail(RT_ERR_INVALID, "rt_debug_leaf_drop: slot out of range");
+        float const* rec = packed + recFloats * (static_cast<size_t>(node_slots) - 1 - slots[i]);
         float const* o = origins + 3 * i;
         float const* d = directions + 3 * i;
         float const rx = 1.0f / d[0], ry = 1.0f / d[1], rz = 1.0f / d[2];
         bool const rayOk = rtFilterMargin(o[0], o[1], o[2], d[0], d[1], d[2], rx, ry, rz, box_abs_max) < INFINITY;
-        out_drop[i] = rtLeafBoundsMiss(rec.lo[0], rec.lo[1], rec.lo[2], rec.hi[0], rec.hi[1], rec.hi[2], rec.cone, rec.cK, rec.cE,
-                                       o[0], o[1], o[2], d[0], d[1], d[2], rx, ry, rz, rayOk) ? 1 : 0;
+        out_drop[i] = rtLeafRecordMiss(rec, static_cast<int>(leaf_axes), o[0], o[1], o[2], d[0], d[1], d[2], rx, ry, rz, rayOk) ? 1 : 0;
     }
     return RT_OK;
 }

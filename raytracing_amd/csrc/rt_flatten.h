@@ -9,13 +9,13 @@
 #include <vector>
 
 struct rt_flat_scene {
-    // `packed` holds, in units of 16 bytes: 3 * frontSlots words of leaf bounds records (48 bytes each, the record of
-    // node slot s at word 3 * (frontSlots - 1 - s)), then 2 * nodeSlots words of node records (32 bytes each).  The
-    // kernels' node pointer is packed + 3 * frontSlots words; the bounds record of slot s then sits at word
-    // -3 * (s + 1) from it.  frontSlots is nodeSlots rounded up to a multiple of four, which keeps child pairs on one
-    // 64-byte line.
+    // `packed` holds the leaf bounds records (64 bytes each, in the form leafAxes says, see rt_leaf_bounds.h), the record of
+    // node slot s at byte 64 * (frontSlots - 1 - s), then the node records (32 bytes each).  The kernels' node pointer is
+    // packed + 64 * frontSlots bytes; the bounds record of slot s then sits 64 * (s + 1) bytes in front of it.  frontSlots
+    // equals nodeSlots.
     std::vector<float> packed;
     uint32_t nodeSlots = 0, frontSlots = 0;
+    uint32_t leafAxes = 1;              // RT_LEAF_AXES_ONE (cone form) or RT_LEAF_AXES_PACKED (axes form)
     std::vector<float> leafTris;        // 12 floats per (leaf, triangle) reference, plus one spare record
     std::vector<uint32_t> leafIds;      // {model, tri, scene-wide triangle, 0} per reference
     std::vector<float> shadeRecs;       // 12 floats per reference: {model, vn1} {vn2, vn3.x} {vn3.yz, 0, 0}

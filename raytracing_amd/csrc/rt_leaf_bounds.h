@@ -19,12 +19,13 @@
 // approaches the plane.
 //
 // Rule.  A leaf's bounds record holds B = (box around its triangles as the test sees them: v1, v1 + e12,
-// v1 + e13) cut to the leaf's box, the cone around its triangles' normals (axis A, threshold q, see
-// coneAllBackFacing in rt_device.hip), and two coefficients computed at scene creation,
+// v1 + e13) cut to the leaf's box, a description of its triangles' normals (one cone, or up to three axes, below),
+// and three coefficients computed at scene creation,
 //     cK = sqrt(3) eps (32 kappaMax + 8)        (dimensionless; eps = 2^-24)
-//     cE = 2 eMax cK                            (a length; eMax the leaf's longest e12 or e13),
-// kappaMax and eMax taken over the leaf's triangles.  For a line (o, d) the leaf is dropped when
-//     the cone proves  g >= gLb > 0  for every triangle of the leaf,
+//     cE = 2 eMax cK                            (a length; eMax the leaf's longest e12 or e13)
+//     cN = 0.999e-6 / nMax                      (nMax the leaf's longest normal),
+// kappaMax, eMax and nMax taken over the leaf's triangles.  For a line (o, d) the leaf is dropped when
+//     a lower bound gLb > 0 on g holds for every triangle of the leaf that passes the facing test,
 //     and the line misses B widened on every side by  P = (cK Dinf + cE) / gLb,
 // Dinf being the largest coordinate distance from o to a point of B.
 //
@@ -34,9 +35,9 @@
 //      fl(e13 . w) = e13.(a x d) + h,  |h| <= 6.5 eps |e13| |a| |d|       (same for e12).
 //  * n is the stored normal, N = e12 x e13 the exact one: |n - N| <= 3.5 eps |e12| |e13|, fl(n.d) = n.d + 3 eps |n||d|,
 //    so the exact denominator N.d differs from the computed one by at most 6.5 eps |e12||e13||d|, a relative
-//    6.5 eps kappa / g, which the rule keeps below 2^-7 (it refuses to drop otherwise).
+//    6.5 eps kappa / g, which the rule keeps below 2^-10 (it refuses to drop when cK / gLb > 2^-7).
 //  * u >= 0 in floating point therefore implies for the exact barycentric coordinate of the exact line
-//      uTrue >= -6.5 eps |e13| |a| / (g |n|) (1 + 2^-6),
+//      uTrue >= -6.5 eps |e13| |a| / (g |n|) (1 + 2^-9),
 //    i.e. the exact plane point lies within 6.5 eps kappa |a| / g of the edge; the same for v; and
 //    fl(u + v) <= 1 implies uTrue + vTrue - 1 <= (13 eps kappa |a| + 10 eps kappa eMax) / (g eMax), i.e. within
 //    13 eps kappa (|a| + eMax) / g of the third edge.  Together: the exact line passes within
@@ -54,22 +55,36 @@
 //  <= P (the coefficients use 32 for 26: second-order terms, the rounding of P and of gLb themselves), and it lies
 //  on the exact line: a line that misses the widened B has no accepted hit in the leaf.
 //
-// The cone gives gLb: with c = |A.d| / (|A||d|) and s = q / |A| >= sin(spread + 0.002), every normal makes an angle of
-// at most acos(c) + asin(s) with +-d, whose cosine is at least c (1 - s^2) - s >= c - s - s^2.  |A| lies in [30, 32]
-// (a point within sqrt(3)/2 of the sphere of radius 31), so  32 |d| gLb = G = |A.d| - (32/30) q (1 + q/30) |d|  is a
-// valid (slightly smaller) bound; the rule needs G >= 2^-5 |d| (gLb >= 2^-10), which also keeps the rounding of G itself
-// (a few eps |A.d|) below one part in a thousand.  A leaf without a cone (A = 0) is never dropped.
+// Three lower bounds on g, the largest is used:
+//  * from one cone (smooth surfaces): every normal lies within b of +-A1, the direction makes the angle alpha with
+//    +-A1, cos(alpha) = |A1.d| / |d|, so every normal makes at most alpha + b with +-d and  g >= cos(alpha + b) =
+//    cos b cos(alpha) - sin b sin(alpha).  The record stores cos b rounded down and sin b rounded up (a part in 2^18 to
+//    spare each, which covers the unit axis' own rounding); |d| sin(alpha) = sqrt(d.d - (A1.d)^2) is evaluated with a
+//    part in 2^10 and 2^-18 d.d added under the root, which covers the rounding of A1.d.
+//  * from up to three axes (boxes, rooms: a few flat faces in a leaf; the form of ALL records of a scene in which enough
+//    leaves are of that kind, chosen at scene creation): every normal lies within b2 of one of +-A1, +-A2, +-A3, so
+//    g >= min_k cos(alpha_k + b2) >= min_k |Ak.d| / |d| - 2 sin b2  (cos(x + y) >= cos x - (1 - cos y) - sin y and
+//    1 - cos y <= sin y).  A leaf with fewer axes repeats the last one; a leaf described by one cone stores its axis
+//    three times and sin b (the bound is valid for it too, and weaker than the angle sum).
+//    A leaf whose normals fit neither description has sin b = 1 (and cos b = 0).
+//  * from the facing test itself: an accepted triangle has |fl(n.d)| >= 1e-6 (src/geometry.hpp:126), so
+//    g >= 1e-6 / (|n| |d|) - 3 eps: small triangles (short normals) cannot be hit at a grazing angle at all.
+//    |d| gLb = cN - 2^-22 |d|.
+// The rule applies when gLb >= 2^-10 and cK / gLb <= 2^-7.  (Normals enter only through |A.d|: a normal and its
+// opposite are the same axis, which is what the triangle test sees too, up to the sign it selects by.)
 //
-// The slab test is evaluated on crossing times scaled by G, which avoids the division: a plane of the widened box
-// is crossed at ((plane -+ P) - o) r, and G times that is fma(plane - o, G, -+M) r with M = P G = (cK Dinf + cE) 32 |d|.
+// The slab test is evaluated on crossing times scaled by G = |d| gLb, which avoids the division: a plane of the widened
+// box is crossed at ((plane -+ P) - o) r, and G times that is fma(plane - o, G, -+M) r with M = P G = (cK Dinf + cE) |d|.
 // Each scaled time carries a relative error below 4 eps; the interval ends are widened by 2^-20.  The caller passes
 // rayOk = every |direction component| >= 2^-16 and finite and the origin finite (filterMargin's condition), so r is
-// finite and no 0 * inf arises.  Any NaN or overflow makes a comparison false, i.e. no drop.
+// finite and no 0 * inf arises.  An overflow (coordinates beyond 2^100 or so) ends in inf - inf = NaN in the final
+// comparison, and a NaN anywhere makes it false: no drop.
 #ifndef RT_LEAF_BOUNDS_H
 #define RT_LEAF_BOUNDS_H
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIP__)
 #define RT_HD __attribute__((host)) __attribute__((device)) inline __attribute__((always_inline))
@@ -90,31 +105,64 @@ RT_HD float rtFilterMargin(float ox, float oy, float oz, float dx, float dy, flo
     return (dMin >= 0x1p-16f && dMax < INFINITY) ? m * rMax : INFINITY;      // false for NaN components too
 }
 
-// cone word layout: count (bits 0-7), q (8-12), A.z (13-18), A.y (19-24), A.x (25-30); bit 31: no cone.
-// Returns true when the leaf may be left unscanned.
-RT_HD bool rtLeafBoundsMiss(float lox, float loy, float loz, float hix, float hiy, float hiz, uint32_t coneWord, float cK,
-                            float cE, float ox, float oy, float oz, float dx, float dy, float dz, float rx, float ry,
-                            float rz, bool rayOk) {
-    float const ax = static_cast<float>(static_cast<int32_t>(coneWord << 1) >> 26);
-    float const ay = static_cast<float>(static_cast<int32_t>(coneWord << 7) >> 26);
-    float const az = static_cast<float>(static_cast<int32_t>(coneWord << 13) >> 26);
-    float const q = static_cast<float>((coneWord >> 8) & 0x1Fu);
-    float const ad = fmaf(ax, dx, fmaf(ay, dy, az * dz));
-    float const dlen = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-    float const qf = q * fmaf(q, 32.0f / 900.0f, 32.0f / 30.0f);          // (32/30) q (1 + q/30)
-    float const G = fabsf(ad) - qf * dlen;                                 // 32 |d| gLb
+// |d| gLb from a record's description of the normals.  One-cone form (RT_LEAF_AXES_ONE records): sinB, cosB, axis A1.
+RT_HD float rtLeafGCone(float sinB, float cosB, float a1x, float a1y, float a1z, float dx, float dy, float dz, float dd) {
+    float const ad1 = fabsf(fmaf(a1x, dx, fmaf(a1y, dy, a1z * dz)));         // |d| cos(alpha_1)
+    float const cr = sqrtf(fmaf(fmaxf(fmaf(-ad1, ad1, dd), 0.0f), 1.0f + 0x1p-10f, 0x1p-18f * dd));      // >= |d| sin(alpha_1)
+    return fmaf(cosB, ad1, -(sinB * cr));
+}
+// Axes form (RT_LEAF_AXES_PACKED records, same length): sin b2 as an unsigned 16-bit fraction (unit = 65536, rounded up) and
+// three axes as signed 16-bit components (unit length = 32767), ten halves in the five words that hold {sinB, cosB, A1}
+// in the cone form:
+//   word 0: sin b2 | A1.x << 16   word 1: A1.y | A1.z << 16   word 2: A2.x | A2.y << 16   word 3: A2.z | A3.x << 16
+//   word 4: A3.y | A3.z << 16
+// The quantisation moves an axis by less than 2^-15 rad, which the stored sin b2 allows for; dividing by 32768 instead of
+// the quantised axis' own length (at most 32767 + 1) only lowers the bound.
+#define RT_LEAF_AXES_ONE 1
+#define RT_LEAF_AXES_PACKED 3
+RT_HD float rtLeafSnorm16(uint32_t word, int high) {
+    return static_cast<float>(static_cast<int32_t>(high ? word : word << 16) >> 16);
+}
+RT_HD float rtLeafGPacked(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, float dx, float dy, float dz, float dlen) {
+    float const sin2 = static_cast<float>(w0 & 0xFFFFu) * 0x1p-15f;          // 2 sin b2
+    float const ad1 = fabsf(fmaf(rtLeafSnorm16(w0, 1), dx, fmaf(rtLeafSnorm16(w1, 0), dy, rtLeafSnorm16(w1, 1) * dz)));
+    float const ad2 = fabsf(fmaf(rtLeafSnorm16(w2, 0), dx, fmaf(rtLeafSnorm16(w2, 1), dy, rtLeafSnorm16(w3, 0) * dz)));
+    float const ad3 = fabsf(fmaf(rtLeafSnorm16(w3, 1), dx, fmaf(rtLeafSnorm16(w4, 0), dy, rtLeafSnorm16(w4, 1) * dz)));
+    return fmaf(-sin2, dlen, fminf(fminf(ad1, ad2), ad3) * 0x1p-15f);
+}
+
+// The rule, given gN = |d| gLb from the normals' description.  Record fields: box lo/hi; cK, cE, cN as above.  Returns
+// true when the leaf may be left unscanned.
+RT_HD bool rtLeafBoundsMiss(float lox, float loy, float loz, float hix, float hiy, float hiz, float cK, float cE, float cN,
+                            float gN, float dlen, float ox, float oy, float oz, float rx, float ry, float rz, bool rayOk) {
+    float const G = fmaxf(gN, fmaf(-0x1p-22f, dlen, cN));                   // |d| gLb
     float const lx = lox - ox, ly = loy - oy, lz = loz - oz, hx = hix - ox, hy = hiy - oy, hz = hiz - oz;
     float const dinf = fmaxf(fmaxf(fmaxf(fabsf(lx), fabsf(hx)), fmaxf(fabsf(ly), fabsf(hy))), fmaxf(fabsf(lz), fabsf(hz)));
-    float const scale = 32.0f * dlen;
-    float const M = fmaf(cK, dinf, cE) * scale;                            // P G
-    bool const valid = rayOk && static_cast<int32_t>(coneWord) >= 0 && G >= 0x1p-5f * dlen && cK * scale <= 0x1p-7f * G
-                    && dinf < 0x1p100f && M < INFINITY;
+    float const M = fmaf(cK, dinf, cE) * dlen;                              // P G
+    bool const valid = rayOk && G >= fmaxf(0x1p-10f, 0x1p7f * cK) * dlen;
     float const tax = fmaf(lx, G, -M) * rx, tbx = fmaf(hx, G, M) * rx;
     float const tay = fmaf(ly, G, -M) * ry, tby = fmaf(hy, G, M) * ry;
     float const taz = fmaf(lz, G, -M) * rz, tbz = fmaf(hz, G, M) * rz;
     float const tn = fmaxf(fmaxf(fminf(tax, tbx), fminf(tay, tby)), fminf(taz, tbz));
     float const tf = fminf(fminf(fmaxf(tax, tbx), fmaxf(tay, tby)), fmaxf(taz, tbz));
     return valid && (tn - fabsf(tn) * 0x1p-20f > tf + fabsf(tf) * 0x1p-20f);
+}
+
+// A bounds record as stored, 16 floats (words 6, 7 and, in the axes form, 11-15 hold integers):
+//   {lo.xyz, hi.x} {hi.yz, cone word, leaf index} {cK, cE, cN, sinB | packed} {cosB, A1.xyz | packed}
+RT_HD bool rtLeafRecordMiss(const float* rec, int axes, float ox, float oy, float oz, float dx, float dy, float dz, float rx,
+                            float ry, float rz, bool rayOk) {
+    float const dd = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    float const dlen = sqrtf(dd);
+    float gN;
+    if (axes == RT_LEAF_AXES_ONE) gN = rtLeafGCone(rec[11], rec[12], rec[13], rec[14], rec[15], dx, dy, dz, dd);
+    else {
+        uint32_t w[5];
+        memcpy(w, rec + 11, 20);
+        gN = rtLeafGPacked(w[0], w[1], w[2], w[3], w[4], dx, dy, dz, dlen);
+    }
+    return rtLeafBoundsMiss(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[8], rec[9], rec[10], gN, dlen, ox, oy, oz, rx, ry, rz,
+                            rayOk);
 }
 
 #endif

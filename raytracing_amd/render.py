@@ -71,26 +71,32 @@ def serialize_scene(ray_trace_data):
 
 class FlatTree:
     """rt_debug_flatten: the node and leaf bounds records exactly as rt_scene_create uploads them (host only, no GPU).
-    `nodes` is a structured view of the node records, `bounds` of the leaf bounds records, both indexed by node slot."""
+    `nodes` is a structured view of the node records, `bounds` of the leaf bounds records, both indexed by node slot;
+    `leaf_axes` is the form of the bounds records (1: one cone, 3: up to three axes)."""
 
     NODE_DTYPE = np.dtype([("lo", np.float32, 3), ("hi", np.float32, 3), ("index", np.int32), ("aux", np.uint32)])
     BOUNDS_DTYPE = np.dtype([("lo", np.float32, 3), ("hi", np.float32, 3), ("cone", np.uint32), ("index", np.int32),
-                             ("cK", np.float32), ("cE", np.float32), ("pad_", np.float32, 2)])
+                             ("cK", np.float32), ("cE", np.float32), ("cN", np.float32), ("normals", np.uint32, 5)])
 
     def __init__(self, ray_trace_data):
         L = _lib.lib()
         desc, keep = _describe(ray_trace_data)
-        n, slots, front, amax = c_u64(0), c_u32(0), c_u32(0), c_f32(0)
-        _lib.check(L.rt_debug_flatten(ctypes.byref(desc), None, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(front),
+        n, slots, axes, amax = c_u64(0), c_u32(0), c_u32(0), c_f32(0)
+        _lib.check(L.rt_debug_flatten(ctypes.byref(desc), None, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(axes),
                                       ctypes.byref(amax)))
         self.packed = np.zeros(n.value, np.float32)
         _lib.check(L.rt_debug_flatten(ctypes.byref(desc), ptr(self.packed), ctypes.byref(n), ctypes.byref(slots),
-                                      ctypes.byref(front), ctypes.byref(amax)))
+                                      ctypes.byref(axes), ctypes.byref(amax)))
         del keep
-        self.node_slots, self.front_slots, self.box_abs_max = slots.value, front.value, float(amax.value)
-        self.nodes = self.packed[12 * self.front_slots:].view(self.NODE_DTYPE)
-        self.bounds = self.packed[:12 * self.front_slots].view(self.BOUNDS_DTYPE)[::-1][:self.node_slots]
+        self.node_slots, self.leaf_axes, self.box_abs_max = slots.value, axes.value, float(amax.value)
+        self.nodes = self.packed[16 * self.node_slots:].view(self.NODE_DTYPE)
+        self.bounds = self.packed[:16 * self.node_slots].view(self.BOUNDS_DTYPE)[::-1]
         self.leaf_slots = np.nonzero(self.nodes["index"] < 0)[0].astype(np.uint32)
+
+    def described(self):
+        """Per node slot: does the record describe the leaf's normals at all (sin b below 1)?"""
+        n = self.bounds["normals"]
+        return (n[:, 0].view(np.float32) < 1.0) if self.leaf_axes == 1 else ((n[:, 0] & 0xFFFF) < 0xFFFF)
 
     def leaf_drop(self, slots, origins, directions):
         """rt_debug_leaf_drop: would the traversal leave the leaf at node slot slots[i] unscanned for line i?"""
@@ -99,8 +105,8 @@ class FlatTree:
         d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
         assert len(sl) == len(o) == len(d)
         out = np.zeros(len(o), np.uint8)
-        _lib.check(_lib.lib().rt_debug_leaf_drop(ptr(self.packed), c_u32(self.front_slots), c_f32(self.box_abs_max), ptr(sl),
-                                                 ptr(o), ptr(d), c_u64(len(o)), ptr(out)))
+        _lib.check(_lib.lib().rt_debug_leaf_drop(ptr(self.packed), c_u32(self.node_slots), c_u32(self.leaf_axes),
+                                                 c_f32(self.box_abs_max), ptr(sl), ptr(o), ptr(d), c_u64(len(o)), ptr(out)))
         return out.astype(bool)
 
 
@@ -209,6 +215,18 @@ class DeviceScene:
         _lib.check(_lib.lib().rt_intersect(self._h, ptr(o), ptr(d), c_u64(len(o)), c_f32(t_min),
                                            c_int(mode), ptr(out)))
         return out
+
+    def intersect_check(self, origins, directions, t_min=RAY_INTERSECTION_T_MIN, front_only=True):
+        """rt_intersect_check: the same hits through the kernels that count work and cross-check every conservative
+        shortcut against the exact evaluation; returns (hits, stats dict)."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        out = np.zeros(len(o), _lib.HIT_DTYPE)
+        st = _lib.RtStats()
+        _lib.check(_lib.lib().rt_intersect_check(self._h, ptr(o), ptr(d), c_u64(len(o)), c_f32(t_min),
+                                                 c_int(_lib.RT_INTERSECT_FRONT_ONLY if front_only else 0), ptr(out),
+                                                 ctypes.byref(st)))
+        return out, st.as_dict()
 
     def intersect_device(self, d_origins, d_directions, n, d_out, t_min=RAY_INTERSECTION_T_MIN, front_only=True,
                          stream=None):

@@ -63,7 +63,7 @@ def check_scene(O, rng, scale, lines_per_triangle, targets, max_leaf_tris, verbo
 
     od = [grazing.grazing_lines(rng, t, lines_per_triangle, scale) for t in tris]
     o = np.concatenate([x[0] for x in od]); d = np.concatenate([x[1] for x in od])
-    res = dict(pairs=0, hits=0, wrong=0, wrong_fixed=0, dropped=0, dropped_fixed=0, free=0, cones=int((((flat.bounds[slots]["cone"] >> 13) & 0x3FFFF) != 0).sum()), leaves=len(slots))
+    res = dict(pairs=0, hits=0, wrong=0, wrong_fixed=0, dropped=0, dropped_fixed=0, free=0, cones=int(flat.described()[slots].sum()), leaves=len(slots))
     for f in SHRINK[1:]:
         res[f"wrong_at_{f}"] = 0
     shrunk = []
