@@ -265,6 +265,10 @@ int rt_debug_flatten(const rt_scene_desc* desc, float* packed, uint64_t* packed_
                      uint32_t* leaf_axes, float* box_abs_max);
 int rt_debug_leaf_drop(const float* packed, uint32_t node_slots, uint32_t leaf_axes, float box_abs_max, const uint32_t* slots,
                        const float* origins, const float* directions, uint64_t n, uint8_t* out_drop);
+/* The same for the leaf normal cones: would the traversal skip a leaf whose node record's aux word is cone_words[i] for
+ * direction i, because the cone says that every triangle of the leaf fails the facing test (Surfaces::FRONT_ONLY,
+ * src/geometry.hpp:129-131)? */
+int rt_debug_cone_skip(const uint32_t* cone_words, const float* directions, uint64_t n, uint8_t* out_skip);
 
 const char* rt_last_error(void);
 /* Library/ABI version, bumped on any layout change of the structs above. */

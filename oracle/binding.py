@@ -267,6 +267,15 @@ class Scene:
                                  _c.c_int(int(bool(front_only))), _p(out), _p(t))
         return out.astype(bool), t
 
+    def leaf_facing_counts(self, leaves, directions):
+        """C oracle only: per line, how many triangles of leaf leaves[i] pass the FRONT_ONLY facing test."""
+        assert not self.L.is_ref
+        lv = np.ascontiguousarray(leaves, np.uint32)
+        d = np.ascontiguousarray(directions, np.float32)
+        out = np.zeros(len(lv), np.uint32)
+        self.L.lib.orc_leaf_facing_counts(self.h, _p(lv), _p(d), _c.c_size_t(len(lv)), _p(out))
+        return out
+
     def set_bvh4(self, nodes, tri_order):
         """C oracle only: hand over the product's bounding volume hierarchy (64-byte nodes, triangle order) for the
         restated traversal (intersect(use_bvh=True), render_params(flags=FLAG_ACCEL_BVH))."""

@@ -931,6 +931,20 @@ void orc_leaf_hits(const orc_scene* s, const uint32_t* leaves, const float* boxe
     }
 }
 
+/* How many triangles of leaf leaves[i] pass the facing test of lineTrisIntersection<FRONT_ONLY> for direction i:
+ * negDet = dot(normal, direction) <= -1e-6 (src/geometry.hpp:118,129-131).  Used to check the product's leaf normal cones. */
+void orc_leaf_facing_counts(const orc_scene* s, const uint32_t* leaves, const float* directions, size_t n, uint32_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t count = 0;
+        if (leaves[i] < s->leafCount) {
+            const bsp_leaf* leaf = &s->leaves[leaves[i]];
+            v3 d = ld3(directions + 3 * i);
+            for (uint32_t k = 0; k < leaf->count; ++k) count += simd_dot(s->refTris[leaf->first + k].normal, d) <= -1e-6f;
+        }
+        out[i] = count;
+    }
+}
+
 /* src/render.hpp:227: normalize(pixelToRay * vec3{sx, sy, 1}) with glm's mat3*vec3
  * (libraries/glm/glm/detail/type_mat3x3.inl:468-474). */
 static inline v3 camera_ray(const float* m, float sx, float sy) {

@@ -103,6 +103,8 @@ void orc_intersect(const orc_scene*, const float* origins, const float* directio
  * nearest accepted one with t >= tMin wins, among equal t the lowest scene-wide index. */
 void orc_intersect_brute(const orc_scene*, const float* origins, const float* directions, size_t n, float tMin,
                          int frontOnly, float* outFloats, uint32_t* outIds);
+/* Triangles of leaf leaves[i] that pass the FRONT_ONLY facing test (src/geometry.hpp:118,129-131) for direction i. */
+void orc_leaf_facing_counts(const orc_scene*, const uint32_t* leaves, const float* directions, size_t n, uint32_t* out);
 /* visitLeaf alone (src/bsp.hpp:58-104) for line i and leaf leaves[i] with leaf box boxes[6 i ..]: out[i] = 1 when the
  * scan yields a hit, outT[i] (optional) its t. */
 void orc_leaf_hits(const orc_scene*, const uint32_t* leaves, const float* boxes, const float* origins, const float* directions,

@@ -221,17 +221,7 @@ __device__ __forceinline__ bool originInsideRule(int filterBits, float mu, V3 o,
 //   count in bits 0-30 and no cone.
 __device__ __forceinline__ uint32_t leafTriCount(uint32_t aux) { return (aux & 0x80000000u) ? (aux & 0x7FFFFFFFu) : (aux & 0xFFu); }
 
-__device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) {
-    float const ax = static_cast<float>(static_cast<int32_t>(aux << 1) >> 26);
-    float const ay = static_cast<float>(static_cast<int32_t>(aux << 7) >> 26);
-    float const az = static_cast<float>(static_cast<int32_t>(aux << 13) >> 26);
-    float const q = static_cast<float>((aux >> 8) & 0x1Fu);
-    float const ad = __fmaf_rn(ax, d.x, __fmaf_rn(ay, d.y, az * d.z));
-    float const dd = __fmaf_rn(d.x, d.x, __fmaf_rn(d.y, d.y, d.z * d.z));
-    // a direction so long that the squares overflow, or so short that they underflow, decides nothing
-    float const lhs = ad * ad, rhs = (q * q) * dd;
-    return static_cast<int32_t>(aux) >= 0 && ad > 0.0f && lhs >= rhs && lhs < INFINITY && rhs >= 0x1p-100f;
-}
+__device__ __forceinline__ bool coneAllBackFacing(uint32_t aux, V3 d) { return rtConeAllBackFacing(aux, d.x, d.y, d.z); }      // rt_leaf_bounds.h
 
 // ---- leaf triangle bounds --------------------------------------------------------------------------------
 // A leaf's box is a cell of the spatial subdivision; its triangles usually fill a fraction of it (0.4-0.5 of the volume

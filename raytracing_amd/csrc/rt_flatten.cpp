@@ -483,4 +483,12 @@ int rt_debug_leaf_drop(const float* packed, uint32_t node_slots, uint32_t leaf_a
     return RT_OK;
 }
 
+// Would the traversal skip a leaf whose aux word is cone_words[i] for direction i, on the strength of its normal cone?
+int rt_debug_cone_skip(const uint32_t* cone_words, const float* directions, uint64_t n, uint8_t* out_skip) {
+    if (!cone_words || !directions || !out_skip) return fail(RT_ERR_INVALID, "rt_debug_cone_skip: null argument");
+    for (uint64_t i = 0; i < n; ++i)
+        out_skip[i] = rtConeAllBackFacing(cone_words[i], directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]) ? 1 : 0;
+    return RT_OK;
+}
+
 }  // extern "C"

@@ -105,6 +105,21 @@ RT_HD float rtFilterMargin(float ox, float oy, float oz, float dx, float dy, flo
     return (dMin >= 0x1p-16f && dMax < INFINITY) ? m * rMax : INFINITY;      // false for NaN components too
 }
 
+// Leaf normal cone (a leaf's aux word: count in bits 0-7, q in 8-12, A.z 13-18, A.y 19-24, A.x 25-30; bit 31: no cone): true
+// when every triangle of the leaf fails the facing test for direction d (Surfaces::FRONT_ONLY, src/geometry.hpp:129-131),
+// i.e. when A . d >= q |d|; see the comment above coneAllBackFacing in rt_device.hip for the argument.
+RT_HD bool rtConeAllBackFacing(uint32_t aux, float dx, float dy, float dz) {
+    float const ax = static_cast<float>(static_cast<int32_t>(aux << 1) >> 26);
+    float const ay = static_cast<float>(static_cast<int32_t>(aux << 7) >> 26);
+    float const az = static_cast<float>(static_cast<int32_t>(aux << 13) >> 26);
+    float const q = static_cast<float>((aux >> 8) & 0x1Fu);
+    float const ad = fmaf(ax, dx, fmaf(ay, dy, az * dz));
+    float const dd = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    // a direction so long that the squares overflow, or so short that they underflow, decides nothing
+    float const lhs = ad * ad, rhs = (q * q) * dd;
+    return static_cast<int32_t>(aux) >= 0 && ad > 0.0f && lhs >= rhs && lhs < INFINITY && rhs >= 0x1p-100f;
+}
+
 // |d| gLb from a record's description of the normals.  One-cone form (RT_LEAF_AXES_ONE records): sinB, cosB, axis A1.
 RT_HD float rtLeafGCone(float sinB, float cosB, float a1x, float a1y, float a1z, float dx, float dy, float dz, float dd) {
     float const ad1 = fabsf(fmaf(a1x, dx, fmaf(a1y, dy, a1z * dz)));         // |d| cos(alpha_1)

@@ -93,6 +93,15 @@ class FlatTree:
         self.bounds = self.packed[:16 * self.node_slots].view(self.BOUNDS_DTYPE)[::-1]
         self.leaf_slots = np.nonzero(self.nodes["index"] < 0)[0].astype(np.uint32)
 
+    def cone_skip(self, slots, directions):
+        """rt_debug_cone_skip: would the traversal skip the leaf at node slot slots[i] for direction i because its normal
+        cone says no triangle faces the line?"""
+        words = np.ascontiguousarray(self.nodes["aux"][np.asarray(slots, np.int64)], np.uint32)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        out = np.zeros(len(d), np.uint8)
+        _lib.check(_lib.lib().rt_debug_cone_skip(ptr(words), ptr(d), c_u64(len(d)), ptr(out)))
+        return out.astype(bool)
+
     def described(self):
         """Per node slot: does the record describe the leaf's normals at all (sin b below 1)?"""
         n = self.bounds["normals"]
