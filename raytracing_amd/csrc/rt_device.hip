@@ -1463,7 +1463,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
             uint32_t start = 0;
             if (lane == 0) start = atomicAdd(&P.counts[bounce + 1], staged);
             start = __builtin_amdgcn_readfirstlane(start);
+            // lanes read entries other lanes of the wave wrote above: order the LDS writes before the reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (uint32_t k = lane; k < staged; k += 64) qout[start + k] = stage[k];
+            __builtin_amdgcn_wave_barrier();          // the next step's writes must not overtake these reads
             staged = 0;
         }
     }
@@ -1471,6 +1476,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
         uint32_t start = 0;
         if (lane == 0) start = atomicAdd(&P.counts[bounce + 1], staged);
         start = __builtin_amdgcn_readfirstlane(start);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (uint32_t k = lane; k < staged; k += 64) qout[start + k] = stage[k];
     }
     unsigned long long const s = waveSum(shaded);
@@ -1609,6 +1617,7 @@ struct rt_scene {
     void* dBvhIds = nullptr;
     void* dBvhShade = nullptr;
     uint32_t bvhStackNeed = 0, bvhNodeCount = 0;
+    uint64_t bvhBytes = 0;               // the hierarchy's share of deviceBytes
     bool bvhMerged = false;              // which traversal shape the hierarchy's size calls for (see attachBvh)
     int gridTraceBvh[2][2] = {{0, 0}, {0, 0}};          // [count][spill], for the shape chosen
     int gridIntersectBvh[2][2] = {{0, 0}, {0, 0}};
@@ -1635,6 +1644,8 @@ namespace {
 
 std::mutex g_scratchMutex;
 void* g_scratchPtr[RT_MAX_DEVICES] = {};      // device address of `scratch` on each GPU, resolved once per device
+hipStream_t g_scratchStream[RT_MAX_DEVICES] = {};      // the stream of the last rt_render_device_static call on each GPU
+bool g_scratchHasStream[RT_MAX_DEVICES] = {};
 
 // Resolves this GPU's address of `scratch` (the device must be current) and carves the workspace out of it.
 int bindStaticWorkspace(rt_scene* s) {
@@ -1827,6 +1838,8 @@ void freeBvh(rt_scene* s) {
         if (p) (void)hipFree(p);
     s->dBvhNodes = s->dBvhTris = s->dBvhIds = s->dBvhShade = nullptr;
     s->hasBvh = false;
+    s->deviceBytes -= s->bvhBytes;
+    s->bvhBytes = 0;
 }
 
 int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, uint32_t nodeCount, const uint32_t* order) {
@@ -1908,6 +1921,7 @@ int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, ui
         hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 128));
         if (e != hipSuccess) return e;
         s->deviceBytes += bytes;
+        s->bvhBytes += bytes;
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     hipError_t e = upload(&s->dBvhNodes, nodes, sizeof(rt_bvh4_node) * static_cast<size_t>(nodeCount));
@@ -2377,24 +2391,36 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, float* d_out, rt_st
 }
 
 int rt_render_device_static(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* stats, void* hip_stream) {
-    int const rc = checkRenderParams(s, p, d_out);
-    if (rc != RT_OK) return rc;
-    uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
-    if (pixels > RT_STATIC_MAX_PATHS)
-        return fail(RT_ERR_LIMIT, "rt_render_device_static: rectangle larger than 262144 pixels (RT_STATIC_MAX_PIXELS)");
-    if (p->flags & RT_FLAG_PROFILE_KERNELS)
-        return fail(RT_ERR_INVALID, "rt_render_device_static: RT_FLAG_PROFILE_KERNELS creates events and is not available here");
-    if (p->flags & RT_FLAG_SORT_RAYS)
-        return fail(RT_ERR_INVALID, "rt_render_device_static: RT_FLAG_SORT_RAYS needs buffers outside the static workspace and is not available here");
-    if (!s->wsStatic.A) return fail(RT_ERR_LIMIT, "rt_render_device_static: no static workspace on this device index");
-    HIP_TRY(hipSetDevice(s->device));
-    hipStream_t const st = static_cast<hipStream_t>(hip_stream);
-    int const rcs = adoptStream(s, st);
-    if (rcs != RT_OK) return rcs;
-    uint64_t maxPaths = RT_STATIC_MAX_PATHS;
-    if (p->max_batch_paths) maxPaths = std::min<uint64_t>(maxPaths, std::max<uint64_t>(p->max_batch_paths, pixels));
-    uint32_t const spb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(p->spp, maxPaths / pixels)));
-    return renderCore(s, p, d_out, stats, st, s->wsStatic, spb, false);
+    // (guarded: fail() builds a std::string, and nothing may cross the C ABI as an exception)
+    return guarded("rt_render_device_static", [&]() -> int {
+        int const rc = checkRenderParams(s, p, d_out);
+        if (rc != RT_OK) return rc;
+        uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
+        if (pixels > RT_STATIC_MAX_PATHS)
+            return fail(RT_ERR_LIMIT, "rt_render_device_static: rectangle larger than 262144 pixels (RT_STATIC_MAX_PIXELS)");
+        if (p->flags & RT_FLAG_PROFILE_KERNELS)
+            return fail(RT_ERR_INVALID, "rt_render_device_static: RT_FLAG_PROFILE_KERNELS creates events and is not available here");
+        if (p->flags & RT_FLAG_SORT_RAYS)
+            return fail(RT_ERR_INVALID, "rt_render_device_static: RT_FLAG_SORT_RAYS needs buffers outside the static workspace and is not available here");
+        if (!s->wsStatic.A) return fail(RT_ERR_LIMIT, "rt_render_device_static: no static workspace on this device index");
+        HIP_TRY(hipSetDevice(s->device));
+        hipStream_t const st = static_cast<hipStream_t>(hip_stream);
+        int const rcs = adoptStream(s, st);
+        if (rcs != RT_OK) return rcs;
+        {
+            // Every scene handle on this GPU shares the one array: a call that arrives on another stream than the array's
+            // previous user (whichever handle that was) first waits for that stream.  Calls issued concurrently from
+            // several host threads still race; that is the caller's to avoid.
+            std::lock_guard<std::mutex> lock(g_scratchMutex);
+            if (g_scratchHasStream[s->device] && g_scratchStream[s->device] != st) HIP_TRY(hipStreamSynchronize(g_scratchStream[s->device]));
+            g_scratchStream[s->device] = st;
+            g_scratchHasStream[s->device] = true;
+        }
+        uint64_t maxPaths = RT_STATIC_MAX_PATHS;
+        if (p->max_batch_paths) maxPaths = std::min<uint64_t>(maxPaths, std::max<uint64_t>(p->max_batch_paths, pixels));
+        uint32_t const spb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(p->spp, maxPaths / pixels)));
+        return renderCore(s, p, d_out, stats, st, s->wsStatic, spb, false);
+    });
 }
 
 int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* stats) {

@@ -20,14 +20,19 @@ def test_static_workspace_render_matches_allocating_render():
         w, h = 640, 400
         p2r = sc.pixel_to_ray_transform(w, h)
         stream = torch.cuda.current_stream().cuda_stream
+        free_before = None
         for rect, spp in (((0, 0, 640, 400), 5), ((33, 17, 301, 150), 3)):
             n = rect[2] * rect[3] * 3
             p = ds.make_params(w, h, sc.camera.position, p2r, spp=spp, seed=31, rect=rect, flags=_lib.RT_FLAG_COUNT_WORK)
             want = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
             got = torch.full((n,), -2.0, dtype=torch.float32, device="cuda")
             st_want = ds.render_device(p, want, stream=stream)
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info()[0]
             st_got = ds.render_device_static(p, got, stream=stream)
             torch.cuda.synchronize()
+            # nothing was allocated (or freed) on the device by the static call
+            assert torch.cuda.mem_get_info()[0] == free_before
             assert same_bits(got.cpu().numpy(), want.cpu().numpy())
             for key in ("paths", "segments", "shaded_hits", "box_tests", "tris_tested", "leaf_visits", "inode_visits"):
                 assert st_got[key] == st_want[key], key
