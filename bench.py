@@ -98,6 +98,35 @@ def cpu_baseline(scene, width, height, bounce_limit, target_seconds=12.0):
             "segments_per_path": st["segments"] / st["paths"]}
 
 
+def image_rel_rmse(device, spp=4096):
+    """The metric's second half: the image against the reference's converged render.  The reference's own 16384-spp
+    render of its built-in scene at 160x120 (tests/golden/builtin_converged_160x120.npz, written from the compiled
+    reference: render(), src/render.hpp:215-234) against a GPU render of the same scene and size at `spp` samples
+    (another sampler, so the two are independent estimates of one image): relative RMSE ||a - b|| / ||b|| over the linear
+    HDR frame, beside the value two unbiased estimates of this scene are expected to show, 1.17 sqrt(1/n1 + 1/n2)
+    (the constant was measured with the reference's own sampler at 64 to 1024 spp).  Untimed."""
+    from raytracing_amd import scenes
+    from raytracing_amd.render import DeviceScene, RayTraceData
+    path = os.path.join(ROOT, "tests", "golden", "builtin_converged_160x120.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    ref = g["image"].astype(np.float64)
+    sc = scenes.builtin_scene(3).preprocess()
+    ds = DeviceScene(RayTraceData(sc), device=device)
+    try:
+        img, _ = ds.render(ds.make_params(160, 120, sc.camera.position, sc.pixel_to_ray_transform(160, 120), spp=spp, seed=2024))
+    finally:
+        ds.close()
+    img = img.astype(np.float64)
+    ref_spp = int(g["spp"][0])
+    return {"value": float(np.sqrt(((img - ref) ** 2).sum() / (ref ** 2).sum())),
+            "expected_for_unbiased_estimates": 1.17 * float(np.sqrt(1.0 / spp + 1.0 / ref_spp)),
+            "mean_radiance_ratio": float(img.mean() / ref.mean()), "spp": spp, "reference_spp": ref_spp,
+            "scene": "reference built-in scene (src/main.cpp:134-187), 160x120, linear HDR",
+            "reference": "compiled reference's render() at 16384 spp (tests/golden/builtin_converged_160x120.npz)"}
+
+
 def roofline(workload, work, seg_per_launch, launch_ms, trace_share, accel="bsp"):
     """Ceilings for k_trace, the dominant kernel.  Live inputs: segments per launch and the average launch
     duration (HIP events around every k_trace launch of the timed steps) and the work counters of an untimed
@@ -135,6 +164,7 @@ def roofline(workload, work, seg_per_launch, launch_ms, trace_share, accel="bsp"
         d = pmc.get("k_trace_per_segment", {})
         peaks = pmc.get("peaks_unprofiled", {})
         out["counters_file"] = os.path.relpath(pmc_file, ROOT)
+        out["counters_spp"] = pmc.get("spp")          # the counter passes render the workload's frame at this many samples
         sq = next((v.get("sq", {}) for k, v in pmc.get("kernels", {}).items() if k.startswith(d.get("kernel", "k_trace"))), {})
         if sq.get("SQ_BUSY_CU_CYCLES"):
             # both counters tick once per four clocks; their ratio is the mean number of waves resident per SIMD
@@ -364,6 +394,11 @@ def main():
                 "accelerator": "4-wide bounding volume hierarchy, 64-byte quantised nodes (RT_FLAG_ACCEL_BVH); not the reference's",
                 "value": seg_alt / dt_alt / 1e6, "unit": "Mrays/s", "steps": args.steps, "ms_per_step": dt_alt / args.steps * 1e3,
                 "build_and_upload_s": build_s, "image_finite": bool(torch.isfinite(frame).all())}
+        if world == 1:
+            rmse = image_rel_rmse(local_rank)
+            if rmse is not None:
+                line["image_rel_rmse"] = rmse["value"]
+                line["image_rel_rmse_detail"] = rmse
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, width, height, bounce_limit)
         print(json.dumps(line), flush=True)
