@@ -59,12 +59,22 @@ double seconds(std::chrono::steady_clock::time_point a, std::chrono::steady_cloc
 
 int main(int argcAll, char** argvAll) {
     // "--bvh" anywhere on the command line: render through the alternative accelerator (RT_FLAG_ACCEL_BVH);
-    // "--gpu-build": build the BSP tree with rt_bsp_build_device (the same tree)
+    // "--gpu-build": build the BSP tree with rt_bsp_build_device (the same tree);
+    // "--devices=0,1,...": share the frame's rows out among these GPUs (rt::RenderOptions::devices, rt_render_multi)
     std::vector<char*> args;
     bool hierarchy = false, gpuBuild = false;
+    std::vector<int> devices;
     for (int i = 0; i < argcAll; ++i) {
-        if (i > 0 && std::string(argvAll[i]) == "--bvh") hierarchy = true;
-        else if (i > 0 && std::string(argvAll[i]) == "--gpu-build") gpuBuild = true;
+        std::string const a = argvAll[i];
+        if (i > 0 && a == "--bvh") hierarchy = true;
+        else if (i > 0 && a == "--gpu-build") gpuBuild = true;
+        else if (i > 0 && a.rfind("--devices=", 0) == 0) {
+            for (std::size_t at = 10; at < a.size();) {
+                devices.push_back(std::atoi(a.c_str() + at));
+                std::size_t const comma = a.find(',', at);
+                at = comma == std::string::npos ? a.size() : comma + 1;
+            }
+        }
         else args.push_back(argvAll[i]);
     }
     int const argc = static_cast<int>(args.size());
@@ -73,6 +83,8 @@ int main(int argcAll, char** argvAll) {
     unsigned const height = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 1080;
     rt::RenderOptions options;
     options.boundingVolumeHierarchy = hierarchy;
+    options.devices = devices;
+    if (!devices.empty()) options.device = devices.front();
     if (argc > 3) options.pixelSampleRate = std::strtoul(argv[3], nullptr, 10);
     if (argc > 4) options.seed = std::strtoull(argv[4], nullptr, 10);
     std::string const output = argc > 5 ? argv[5] : "output.ppm";

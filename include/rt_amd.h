@@ -224,6 +224,19 @@ int rt_render(rt_scene* scene, const rt_render_params* params, float* out_rgb, r
 int rt_render_device(rt_scene* scene, const rt_render_params* params, float* d_out_rgb, rt_stats* stats,
                      void* hip_stream);
 
+/* render() on several GPUs from one process (the reference's render() is one call from one thread, src/render.hpp:215-234,
+ * src/main.cpp:230; it has no multi-device form).  scenes[k] are handles of the same scene, normally one per GPU (two
+ * handles on one GPU are allowed).  The rectangle's rows are cut into bands dealt round-robin to the handles; every handle
+ * renders all of its bands with one call on its own GPU, all GPUs at once; the bands are copied GPU-to-GPU (peer copies
+ * over xGMI) into the frame on scenes[0]'s GPU.  The image is the one a single rt_render of the rectangle gives, bit for
+ * bit (the sampler is keyed by the pixel's position in the full image).  rt_render_multi copies the frame to host memory,
+ * rt_render_multi_device leaves it at d_out_rgb, a device pointer on scenes[0]'s GPU.  params must describe a plain
+ * rectangle (row_stride 0 or 1); stats are the sums over the handles, ms_total the whole call. */
+int rt_render_multi(rt_scene* const* scenes, uint32_t scene_count, const rt_render_params* params, float* out_rgb,
+                    rt_stats* stats);
+int rt_render_multi_device(rt_scene* const* scenes, uint32_t scene_count, const rt_render_params* params, float* d_out_rgb,
+                           rt_stats* stats);
+
 /* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and same image, bit
  * for bit, but the path state lives in a fixed array inside the library's code object (about 22 MiB per

@@ -17,6 +17,7 @@
 
 #include <array>
 #include <cstdint>
+#include <memory>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -209,6 +210,7 @@ struct RenderOptions {                                     // src/render.hpp:47-
     float rayIntersectionTMin = 1e-3f;
     std::uint64_t seed = std::random_device{}();
     int device = 0;
+    std::vector<int> devices;              // several GPUs: the frame's rows are shared out among them (rt_render_multi); empty: `device` alone
     bool russianRoulette = false;          // RT_FLAG_RUSSIAN_ROULETTE
     bool perLobeSampling = false;          // RT_FLAG_LOBE_SAMPLING
     bool boundingVolumeHierarchy = false;  // RT_FLAG_ACCEL_BVH: the alternative accelerator instead of the BSP tree
@@ -283,7 +285,20 @@ inline void render(DeviceScene& scene, RenderData const& data, Vec3* image, Rend
 }
 
 inline void render(RenderData const& data, Vec3* image, RenderOptions const& options = {}, rt_stats* stats = nullptr) {
-    DeviceScene scene{data.rayTraceData, options.device, options.boundingVolumeHierarchy};
+    if (options.devices.size() > 1) {
+        // one copy of the scene per GPU, one frame shared out among them
+        std::vector<std::unique_ptr<DeviceScene>> scenes;
+        std::vector<rt_scene*> handles;
+        for (int device : options.devices) {
+            scenes.push_back(std::make_unique<DeviceScene>(data.rayTraceData, device, options.boundingVolumeHierarchy));
+            handles.push_back(scenes.back()->handle());
+        }
+        rt_render_params const p = renderParams(data, options);
+        if (rt_render_multi(handles.data(), static_cast<std::uint32_t>(handles.size()), &p, &image->x, stats) != RT_OK)
+            throw std::runtime_error(rt_last_error());
+        return;
+    }
+    DeviceScene scene{data.rayTraceData, options.devices.empty() ? options.device : options.devices.front(), options.boundingVolumeHierarchy};
     render(scene, data, image, options, stats);
 }
 

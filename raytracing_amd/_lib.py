@@ -77,7 +77,7 @@ RT_STATIC_MAX_PIXELS = 262144
 
 # Every symbol declared by include/rt_amd.h and include/rt_host.h.
 DEVICE_SYMBOLS = ["rt_scene_create", "rt_scene_serialize", "rt_scene_desc_from_blob", "rt_scene_create_from_blob", "rt_scene_destroy", "rt_scene_attach_bvh4", "rt_scene_build_bvh4", "rt_scene_info", "rt_intersect", "rt_intersect_device", "rt_intersect_check",
-                  "rt_render", "rt_render_device", "rt_render_device_static", "rt_postprocess", "rt_postprocess_device", "rt_selftest_math",
+                  "rt_render", "rt_render_device", "rt_render_device_static", "rt_render_multi", "rt_render_multi_device", "rt_postprocess", "rt_postprocess_device", "rt_selftest_math",
                   "rt_debug_flatten", "rt_debug_leaf_drop", "rt_debug_cone_skip", "rt_last_error", "rt_abi_version"]
 HOST_SYMBOLS = ["rt_preprocess_material", "rt_quat_from_euler", "rt_camera_basis", "rt_pixel_to_ray_transform",
                 "rt_instantiate_meshes", "rt_preprocess_tris", "rt_instantiate_meshes_device", "rt_preprocess_tris_device", "rt_scene_bounding_box", "rt_line_intersects_box",

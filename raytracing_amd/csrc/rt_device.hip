@@ -1627,6 +1627,8 @@ struct rt_scene {
     // stream of the previous call.
     hipStream_t lastStream = nullptr;
     bool hasLastStream = false;
+    uint32_t lastBatches = 0, lastTraceLaunches = 0;      // of the latest render call (rt_render_multi reads them back)
+    void* wsFrame = nullptr; uint64_t wsFramePixels = 0;   // rt_render_multi: the assembled frame on the first scene's GPU
 };
 
 // ---- allocation-free workspace -------------------------------------------------------------------
@@ -2087,6 +2089,8 @@ int renderCore(rt_scene* s, const rt_render_params* p, float* d_out, rt_stats* s
         ++batches;
     }
     HIP_TRY(hipGetLastError());
+    s->lastBatches = batches;
+    s->lastTraceLaunches = traceLaunches;
     if (stats) {
         Counters hc;
         HIP_TRY(hipMemcpyAsync(&hc, gc, sizeof hc, hipMemcpyDeviceToHost, st));
@@ -2153,7 +2157,7 @@ void rt_scene_destroy(rt_scene* s) {
     freeWorkspace(s);
     freeBvh(s);
     for (void* p : {s->dNodes, s->dLeafTris, s->dLeafIds, s->dTriNormals, s->dMaterials, static_cast<void*>(s->ws.counts),
-                    static_cast<void*>(s->ws.counters), s->wsOut})
+                    static_cast<void*>(s->ws.counters), s->wsOut, s->wsFrame})
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : s->eventPool) (void)hipEventDestroy(ev);
     delete s;
@@ -2421,6 +2425,102 @@ int rt_render_device_static(rt_scene* s, const rt_render_params* p, float* d_out
         uint32_t const spb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(p->spp, maxPaths / pixels)));
         return renderCore(s, p, d_out, stats, st, s->wsStatic, spb, false);
     });
+}
+
+// render() over several GPUs from one process (the reference's render() is one call, src/render.hpp:215-234).  Rows are
+// cut into bands of equal height dealt round-robin to the scenes (eight bands each: a scene's cost per row varies with
+// what the rows show), every scene renders all of its bands with ONE call (row_group / row_stride) on its own GPU, all
+// GPUs working at once, and the finished bands are copied GPU-to-GPU into the frame on the first scene's GPU.
+namespace {
+int renderMulti(rt_scene* const* scenes, uint32_t n, const rt_render_params* p, float* d_frame, float* host_frame, rt_stats* stats) {
+    auto const t0 = std::chrono::steady_clock::now();
+    if (!scenes || n == 0 || !p || (!d_frame && !host_frame)) return fail(RT_ERR_INVALID, "rt_render_multi: null argument");
+    for (uint32_t k = 0; k < n; ++k)
+        if (!scenes[k]) return fail(RT_ERR_INVALID, "rt_render_multi: null scene");
+    if (p->row_stride > 1u) return fail(RT_ERR_INVALID, "rt_render_multi: the rectangle must be plain (row_stride is used internally)");
+    if (p->w == 0 || p->h == 0 || p->spp == 0) return fail(RT_ERR_INVALID, "rt_render: empty rectangle or zero spp");
+    rt_scene* const first = scenes[0];
+    uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
+    size_t const rowBytes = static_cast<size_t>(p->w) * 12;
+    if (!d_frame) {
+        HIP_TRY(hipSetDevice(first->device));
+        if (first->wsFramePixels < pixels) {
+            if (first->hasLastStream) HIP_TRY(hipStreamSynchronize(first->lastStream));
+            if (first->wsFrame) (void)hipFree(first->wsFrame);
+            first->wsFrame = nullptr; first->wsFramePixels = 0;
+            HIP_TRY(hipMalloc(&first->wsFrame, pixels * 12));
+            first->wsFramePixels = pixels;
+        }
+        d_frame = static_cast<float*>(first->wsFrame);
+    }
+    uint32_t const bands = std::max<uint32_t>(1u, std::min<uint32_t>(p->h, n * 8u));
+    uint32_t const group = (p->h + bands - 1) / bands;                  // rows per band (the frame's last band may be shorter)
+    uint32_t const bandCount = (p->h + group - 1) / group;
+    // ---- enqueue every scene's share (no synchronisation: stats are collected afterwards) ----
+    std::vector<uint32_t> rowsOf(n, 0u);
+    for (uint32_t b = 0; b < bandCount; ++b) rowsOf[b % n] += std::min(group, p->h - b * group);
+    for (uint32_t k = 0; k < n; ++k) {
+        if (rowsOf[k] == 0) continue;
+        rt_scene* const s = scenes[k];
+        HIP_TRY(hipSetDevice(s->device));
+        uint64_t const need = static_cast<uint64_t>(rowsOf[k]) * p->w;
+        if (s->wsOutPixels < need) {
+            if (s->hasLastStream) HIP_TRY(hipStreamSynchronize(s->lastStream));
+            if (s->wsOut) (void)hipFree(s->wsOut);
+            s->wsOut = nullptr; s->wsOutPixels = 0;
+            HIP_TRY(hipMalloc(&s->wsOut, need * 12));
+            s->wsOutPixels = need;
+        }
+        rt_render_params q = *p;
+        q.y0 = p->y0 + k * group;
+        q.h = rowsOf[k];
+        q.row_group = group;
+        q.row_stride = n;
+        int const rc = rt_render_device(s, &q, static_cast<float*>(s->wsOut), nullptr, nullptr);
+        if (rc != RT_OK) return rc;
+        // this scene's bands into the frame, behind its render on its own GPU's stream
+        size_t cursor = 0;
+        for (uint32_t b = k; b < bandCount; b += n) {
+            size_t const bytes = static_cast<size_t>(std::min(group, p->h - b * group)) * rowBytes;
+            char* dst = reinterpret_cast<char*>(d_frame) + static_cast<size_t>(b) * group * rowBytes;
+            const char* src = static_cast<const char*>(s->wsOut) + cursor;
+            if (s->device == first->device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, nullptr));
+            else HIP_TRY(hipMemcpyPeerAsync(dst, first->device, src, s->device, bytes, nullptr));
+            cursor += bytes;
+        }
+    }
+    // ---- wait for every GPU, then add up what they counted ----
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    for (uint32_t k = 0; k < n; ++k) {
+        if (rowsOf[k] == 0) continue;
+        rt_scene* const s = scenes[k];
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        if (stats) {
+            Counters hc;
+            HIP_TRY(hipMemcpy(&hc, s->ws.counters, sizeof hc, hipMemcpyDeviceToHost));
+            stats->paths += hc.paths; stats->segments += hc.segments; stats->shaded_hits += hc.shadedHits;
+            stats->box_tests += hc.boxTests; stats->tris_tested += hc.trisTested; stats->leaf_visits += hc.leafVisits;
+            stats->inode_visits += hc.inodeVisits;
+            stats->box_exact_fallbacks += hc.boxFallbacks; stats->box_filter_errors += hc.boxFilterErrors;
+            stats->trace_launches += s->lastTraceLaunches; stats->batches += s->lastBatches;
+        }
+    }
+    if (host_frame) {
+        HIP_TRY(hipSetDevice(first->device));
+        HIP_TRY(hipMemcpy(host_frame, d_frame, pixels * 12, hipMemcpyDeviceToHost));
+    }
+    if (stats) stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+}  // namespace
+
+int rt_render_multi(rt_scene* const* scenes, uint32_t scene_count, const rt_render_params* p, float* out_rgb, rt_stats* stats) {
+    return guarded("rt_render_multi", [&] { return renderMulti(scenes, scene_count, p, nullptr, out_rgb, stats); });
+}
+
+int rt_render_multi_device(rt_scene* const* scenes, uint32_t scene_count, const rt_render_params* p, float* d_out_rgb, rt_stats* stats) {
+    return guarded("rt_render_multi_device", [&] { return renderMulti(scenes, scene_count, p, d_out_rgb, nullptr, stats); });
 }
 
 int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* stats) {

@@ -285,6 +285,16 @@ class DeviceScene:
         return st.as_dict() if want_stats else None
 
 
+def render_multi(device_scenes, params):
+    """rt_render_multi: one frame over several scene handles (normally one per GPU), rows dealt in bands, bands gathered
+    GPU-to-GPU on the first handle's GPU.  Returns (image[h, w, 3] float32 on the host, summed stats)."""
+    handles = (ctypes.c_void_p * len(device_scenes))(*[d._h.value for d in device_scenes])
+    img = np.zeros((params.h, params.w, 3), np.float32)
+    st = _lib.RtStats()
+    _lib.check(_lib.lib().rt_render_multi(handles, c_u32(len(device_scenes)), ctypes.byref(params), ptr(img), ctypes.byref(st)))
+    return img, st.as_dict()
+
+
 class RenderData:
     """src/render.hpp:38-44."""
 

@@ -814,6 +814,11 @@ def test_cpp_host_layer_program_matches_python_path(tmp_path):
     run = subprocess.run([exe, "480", "270", "4", "11", str(out4), "--gpu-build"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stderr[-2000:]
     assert out4.read_bytes() == out.read_bytes()
+    # the frame shared out among two scene handles (rt::RenderOptions::devices -> rt_render_multi; both on this box's one GPU)
+    out5 = tmp_path / "two_handles.ppm"
+    run = subprocess.run([exe, "480", "270", "4", "11", str(out5), "--devices=0,0"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert out5.read_bytes() == out.read_bytes()
 
 
 @pytest.mark.parametrize("accel", ["bsp", "bvh"])
