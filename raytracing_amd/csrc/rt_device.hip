@@ -1536,6 +1536,38 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathState P, float* __r
     }
 }
 
+// How many blocks of the persistent traversal kernels really are resident at once?  The static share of the line stream is
+// dealt out over the grid on the assumption that all of it runs concurrently, and the occupancy query that sizes the grid
+// does not see everything (see RT_PERSISTENT_SGPRS).  This kernel has the traversal kernels' footprint -- 256 threads, the
+// same LDS stack, 64 vector registers, scalar registers in the same allocation bracket -- and does nothing but count:
+// every block announces itself, then waits until the whole grid has been seen alive together or a time limit passes,
+// so the largest number alive at once is the residency.  c[0]: blocks alive, c[1]: the peak, c[2]: set once the whole grid
+// was alive.  Every block leaves when the flag is up or after `timeoutTicks` of the 100 MHz wall clock.
+__global__ __launch_bounds__(RT_BLOCK) RT_PERSISTENT_SGPRS RT_EIGHT_WAVES void k_residency_probe(uint32_t* __restrict__ c, uint32_t target,
+                                                                                              unsigned long long timeoutTicks, int touchExtraLds) {
+    __shared__ uint32_t lds[RT_LDS_STACK_DEPTH * RT_BLOCK];
+    extern __shared__ uint32_t extraLds[];            // measurements: RT_AMD_PROBE_LDS bytes more per block lower the residency
+    lds[threadIdx.x] = target;
+    asm volatile("" ::: "v63", "s70");                 // the register footprint of the traversal kernels
+    if (threadIdx.x == 0) {
+        if (touchExtraLds) extraLds[0] = target;
+        uint32_t alive = atomicAdd(&c[0], 1u) + 1u;
+        atomicMax(&c[1], alive);
+        unsigned long long const t0 = wall_clock64();
+        for (;;) {
+            if (alive >= target) { atomicExch(&c[2], 1u); break; }
+            if (atomicAdd(&c[2], 0u) != 0u) break;
+            if (wall_clock64() - t0 > timeoutTicks) break;
+            __builtin_amdgcn_s_sleep(32);
+            alive = atomicAdd(&c[0], 0u);
+            atomicMax(&c[1], alive);
+        }
+        atomicSub(&c[0], 1u);
+    }
+    __syncthreads();
+    if (lds[threadIdx.x] != target) c[3] = 1u;          // keeps the LDS array alive
+}
+
 // Device-side evaluation of the scalar building blocks, so tests can pin their bits.
 __global__ void k_selftest(int op, const float* __restrict__ a, const float* __restrict__ b, uint32_t n,
                            float* __restrict__ out) {
@@ -1696,9 +1728,42 @@ void freeWorkspace(rt_scene* s) {
     W.pixels = 0;
 }
 
+// Blocks of the traversal kernels' footprint that are resident per CU on this GPU, measured once per device with
+// k_residency_probe (a grid of eight per CU; 0.1 ms when all of it is resident, a few time limits otherwise).
+std::mutex g_probeMutex;
+int g_probedPerCu[RT_MAX_DEVICES] = {};
+
+int probedBlocksPerCu(const rt_scene* s) {
+    int const want = 8;
+    if (s->device < 0 || s->device >= RT_MAX_DEVICES) return want;
+    std::lock_guard<std::mutex> lock(g_probeMutex);
+    if (g_probedPerCu[s->device] > 0) return g_probedPerCu[s->device];
+    uint32_t* d = nullptr;
+    int result = want;
+    if (hipMalloc(&d, 16) == hipSuccess) {
+        uint32_t const grid = static_cast<uint32_t>(s->cuCount * want);
+        size_t extra = 0;
+        if (const char* text = std::getenv("RT_AMD_PROBE_LDS")) extra = std::strtoull(text, nullptr, 10);
+        uint32_t h[4] = {0, 0, 0, 0};
+        if (hipMemset(d, 0, 16) == hipSuccess) {
+            hipLaunchKernelGGL(k_residency_probe, dim3(grid), dim3(RT_BLOCK), extra, nullptr, d, grid, 50000ull /* 0.5 ms */, extra ? 1 : 0);
+            if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess
+                && hipMemcpy(h, d, 16, hipMemcpyDeviceToHost) == hipSuccess && h[1] > 0)
+                result = std::max(1, static_cast<int>(h[2] ? want : h[1] / static_cast<uint32_t>(s->cuCount)));
+        }
+        (void)hipGetLastError();
+        (void)hipFree(d);
+        if (std::getenv("RT_AMD_DEBUG"))
+            std::fprintf(stderr, "rt_amd: residency probe on device %d: %u of %u blocks alive at once -> %d per CU%s\n", s->device, h[1], grid,
+                         result, result < want ? " (fewer than the occupancy query promises: the persistent grids shrink accordingly)" : "");
+    }
+    g_probedPerCu[s->device] = result;
+    return result;
+}
+
 // Resident blocks of a persistent kernel over the whole chip: every block must be resident at once (the
 // static share of the line stream assumes all waves run concurrently), so the cap is the kernel's own
-// occupancy.
+// occupancy -- as the runtime reports it, and no more than the probe has seen.
 template <class Kernel>
 int residentBlocks(const rt_scene* s, Kernel kernel, bool deepTree) {
     int perCu = 0;
@@ -1712,7 +1777,7 @@ int residentBlocks(const rt_scene* s, Kernel kernel, bool deepTree) {
     // 4 k-triangle scene).  RT_AMD_BLOCKS_PER_CU overrides the cap for tuning.
     int cap = deepTree ? 8 : 7;
     if (const char* text = std::getenv("RT_AMD_BLOCKS_PER_CU")) cap = std::max(1, std::atoi(text));
-    return s->cuCount * std::min(perCu, cap);
+    return s->cuCount * std::min(std::min(perCu, cap), probedBlocksPerCu(s));
 }
 
 int persistentGrid(int residentCap, uint64_t items) {

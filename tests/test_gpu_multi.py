@@ -39,3 +39,37 @@ def test_render_multi_equals_single_render(handles):
     finally:
         for d in ds:
             d.close()
+
+
+def test_residency_probe_shrinks_the_persistent_grid(tmp_path):
+    """The persistent traversal kernels deal most of their lines out statically over a grid that must be wholly resident.
+    At scene creation a probe kernel with the traversal kernels' footprint counts how many blocks are alive at once; when
+    that is fewer than the occupancy query promises the grids shrink.  Here the probe is handicapped with extra LDS
+    (RT_AMD_PROBE_LDS), as if the system allowed only two blocks per CU: the library says so under RT_AMD_DEBUG and the
+    frame is the same, bit for bit (a child process each: the probe's answer is kept per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from raytracing_amd import scenes\n"
+        "from raytracing_amd.render import DeviceScene, RayTraceData\n"
+        "sc = scenes.dragon_scale_scene(30000).preprocess()\n"
+        "ds = DeviceScene(RayTraceData(sc))\n"
+        "img, st = ds.render(ds.make_params(640, 360, sc.camera.position, sc.pixel_to_ray_transform(640, 360), spp=4, seed=3))\n"
+        "np.save(sys.argv[1], img)\n"
+        "print('segments', st['segments'])\n")
+    outs = []
+    for name, extra in (("plain", {}), ("handicapped", {"RT_AMD_PROBE_LDS": "40000"})):
+        path = tmp_path / f"{name}.npy"
+        run = subprocess.run([sys.executable, "-c", code, str(path)], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, RT_AMD_DEBUG="1", **extra))
+        assert run.returncode == 0, run.stderr[-2000:]
+        line = [l for l in run.stderr.splitlines() if "residency probe" in l]
+        assert len(line) == 1, run.stderr[-2000:]
+        outs.append((np.load(path), line[0], run.stdout))
+    assert "-> 8 per CU" in outs[0][1] and "fewer than" not in outs[0][1], outs[0][1]
+    assert "-> 2 per CU" in outs[1][1] and "fewer than the occupancy query promises" in outs[1][1], outs[1][1]
+    assert same_bits(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
