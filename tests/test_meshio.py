@@ -132,3 +132,101 @@ def test_bad_files_are_reported(tmp_path):
     empty.write_text("# nothing\n")
     pos, nrm, tris = S.load_mesh(empty)
     assert pos.shape == (0, 3) and tris.shape == (0, 3)
+
+
+# ---- files in the dialects common exporters write ---------------------------------------------------------------------
+# (hand-written here after the formats' published descriptions: Wavefront's OBJ text format and the Stanford PLY header
+# grammar; parity unpinned by construction, since the reference reads no files)
+
+BLENDER_STYLE_OBJ = (
+    "# Blender 3.6.0\r\n"
+    "# www.blender.org\r\n"
+    "mtllib tetra.mtl\r\n"
+    "o Tetra\r\n"
+    "v 0.000000 0.000000 0.000000\r\n"
+    "v 1.000000 0.000000 0.000000 \r\n"          # trailing blank
+    "v\t0.000000\t1.000000\t0.000000\r\n"        # tabs
+    "v 0.000000 0.000000 1.000000 1.0\r\n"       # optional w
+    "vt 0.0 0.0\r\n"
+    "vt 1.0 0.0\r\n"
+    "vt 0.0 1.0\r\n"
+    "vn 0.0 0.0 -1.0\r\n"
+    "vn 0.0 -1.0 0.0\r\n"
+    "vn -1.0 0.0 0.0\r\n"
+    "vn 0.5774 0.5774 0.5774\r\n"
+    "s off\r\n"
+    "g side\r\n"
+    "usemtl Material\r\n"
+    "f 1/1/1 3/3/1 2/2/1\r\n"
+    "f 1/1/2 2/2/2 4/3/2\r\n"
+    "f 1/1/3 4/2/3 3/3/3\r\n"
+    "l 1 2\r\n"                                  # a polyline element: not geometry this reader keeps
+    "f 2/1/4 3/2/4 4/3/4\r\n")
+
+
+def test_obj_as_a_modelling_program_writes_it(tmp_path):
+    path = tmp_path / "tetra.obj"
+    path.write_bytes(BLENDER_STYLE_OBJ.encode())
+    pos, nrm, tris = S.load_mesh(path)
+    assert tris.shape == (4, 3)
+    assert pos.shape == nrm.shape == (12, 3)          # 4 faces x 3 distinct (position, normal) pairs
+    corners = {tuple(p) for p in pos.tolist()}
+    assert corners == {(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)}
+    assert np.allclose(nrm[tris[0]], [0, 0, -1]) and np.allclose(nrm[tris[3]], 0.5774, atol=1e-4)
+
+
+def test_obj_polygon_is_split_into_a_fan_and_texture_only_indices_work(tmp_path):
+    path = tmp_path / "pentagon.obj"
+    path.write_text("v 0 0 0\nv 2 0 0\nv 3 1 0\nv 1 2 0\nv -1 1 0\nvt 0 0\nf 1/1 2/1 3/1 4/1 5/1\n")
+    pos, nrm, tris = S.load_mesh(path)
+    assert tris.tolist() == [[0, 1, 2], [0, 2, 3], [0, 3, 4]]
+    assert np.allclose(nrm, [0, 0, 1])
+
+
+def _ply(header_lines, body, binary=False):
+    head = "ply\nformat %s 1.0\n" % ("binary_little_endian" if binary else "ascii") + "\n".join(header_lines) + "\nend_header\n"
+    return head.encode() + (body if binary else body.encode())
+
+
+def test_ply_with_colours_doubles_and_alternative_property_names(tmp_path):
+    """What scanning and mesh-processing tools write: comments, per-vertex colours and a confidence value between the
+    coordinates and after them, double coordinates, `vertex_index` with uint indices and a per-face flags byte."""
+    header = ["comment VCGLIB generated", "obj_info scanned", "element vertex 4",
+              "property double x", "property double y", "property double z",
+              "property uchar red", "property uchar green", "property uchar blue", "property float confidence",
+              "element face 2", "property uchar flags", "property list uchar uint vertex_index"]
+    verts = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)]
+    ascii_body = "".join(f"{x} {y} {z} 255 128 0 0.5\n" for x, y, z in verts) + "0 3 0 1 2\n0 3 0 2 3\n"
+    path = tmp_path / "a.ply"
+    path.write_bytes(_ply(header, ascii_body))
+    pos, nrm, tris = S.load_mesh(path)
+    assert pos.tolist() == [list(map(float, v)) for v in verts] and tris.tolist() == [[0, 1, 2], [0, 2, 3]]
+    assert np.allclose(nrm, [0, 0, 1])
+    binary_body = b"".join(struct.pack("<dddBBBf", x, y, z, 255, 128, 0, 0.5) for x, y, z in verts)
+    binary_body += struct.pack("<BBIII", 0, 3, 0, 1, 2) + struct.pack("<BBIII", 0, 3, 0, 2, 3)
+    path = tmp_path / "b.ply"
+    path.write_bytes(_ply(header, binary_body, binary=True))
+    pos2, nrm2, tris2 = S.load_mesh(path)
+    assert np.array_equal(pos, pos2) and np.array_equal(tris, tris2) and np.allclose(nrm, nrm2)
+
+
+def test_ply_quads_strips_of_other_elements_and_crlf_header(tmp_path):
+    header = ["element vertex 4", "property float x", "property float y", "property float z",
+              "property float nx", "property float ny", "property float nz",
+              "element face 1", "property list uchar int vertex_indices",
+              "element edge 1", "property int vertex1", "property int vertex2"]
+    body = "0 0 0 0 0 1\n1 0 0 0 0 1\n1 1 0 0 0 1\n0 1 0 0 0 1\n4 0 1 2 3\n0 1\n"
+    text = ("ply\nformat ascii 1.0\n" + "\n".join(header) + "\nend_header\n" + body).replace("\n", "\r\n")
+    path = tmp_path / "quad.ply"
+    path.write_bytes(text.encode())
+    pos, nrm, tris = S.load_mesh(path)
+    assert tris.tolist() == [[0, 1, 2], [0, 2, 3]] and np.allclose(nrm, [0, 0, 1])
+
+
+def test_ply_big_endian_is_refused_with_a_message(tmp_path):
+    path = tmp_path / "be.ply"
+    path.write_bytes(b"ply\nformat binary_big_endian 1.0\nelement vertex 0\nproperty float x\nproperty float y\nproperty float z\n"
+                     b"element face 0\nproperty list uchar int vertex_indices\nend_header\n")
+    with pytest.raises(Exception) as e:
+        S.load_mesh(path)
+    assert "big" in str(e.value).lower() or "endian" in str(e.value).lower()
