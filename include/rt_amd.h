@@ -119,7 +119,11 @@ typedef struct {
  * lies in the root box (ties: lowest triangle index).  Of the BSP leaf's in-box rule (src/bsp.hpp:82-87) only
  * the root box is left, so the two accelerators can differ on a ray whose hit point rounds to just outside an
  * inner leaf's box and inside no other leaf that holds the triangle: none in 469 000 rays of the built-in
- * scene, a few in 100 000 on large meshes.  The converged image is unchanged.  The hierarchy's box test treats a
+ * scene, a few in 100 000 on large meshes.  A second difference: the hierarchy's boxes are the triangles' corners with a
+ * fixed padding, while the reference's triangle test accepts a line that grazes a triangle's plane (|normal . direction|
+ * just above 1e-6) many edge lengths outside the triangle; such hits are found by the BSP path (whose leaf bounds widen
+ * as the line approaches the plane) and can be missed here -- a set of measure about 1e-7 of random rays.  So this is an
+ * alternative accelerator with the reference's converged image, not a bit-exact one.  The hierarchy's box test treats a
  * direction component below 2^-80 in magnitude as zero (the line as parallel to that axis): harmless for a direction
  * of ordinary length, where such a component moves the line by nothing over any finite distance, but a direction
  * that is that short as a whole is outside this accelerator's domain (the BSP path has no such limit). */
