@@ -20,7 +20,7 @@
 // What only shading needs sits in a parallel array, leafIds: {mesh, tri, gtri, 0} with gtri the
 // scene-wide index of the instantiated triangle; keeping it out of the records makes the traversal's
 // working set a quarter smaller.
-// Shading records, 48 bytes stored at a stride of 64 (RT_SHADE_REC_FLOATS: one line of memory per record) per triangle record (same index): {model, vn1.xyz} {vn2.xyz, vn3.x} {vn3.yz, 0, 0} -- the model
+// Shading records, 48 bytes per triangle record (same index): {model, vn1.xyz} {vn2.xyz, vn3.x} {vn3.yz, 0, 0} -- the model
 // (for the material) and the three instantiated vertex normals, so that shading needs one dependent fetch per hit.
 // Material, 48 bytes per model: {ndfAlphaSq geomAlphaSq f0.x f0.y} {f0.z adj.x adj.y adj.z} {em.x em.y em.z 0}.
 struct DevScene {

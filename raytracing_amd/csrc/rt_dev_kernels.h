@@ -299,7 +299,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
                 float const Tz = P.Tz[slot];
                 V3 const o = mk(A.x, A.y, A.z), d = mk(A.w, B.x, B.y);
                 V3 T = mk(B.z, B.w, Tz);
-                float4 const n0 = S.shadeRecs[(RT_SHADE_REC_FLOATS / 4) * static_cast<size_t>(ref)];
+                float4 const n0 = S.shadeRecs[3 * static_cast<size_t>(ref)];
                 uint32_t const mesh = __float_as_uint(n0.x);
                 float4 const m0 = S.materials[3 * mesh], m1 = S.materials[3 * mesh + 1], m2 = S.materials[3 * mesh + 2];
                 float const ndfA = m0.x, geoA = m0.y;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, RenderConst R, P
                 }
                 if (bounce < R.bounceLimit) {                                    // src/render.hpp:117
                     ++shaded;
-                    float4 const n1 = S.shadeRecs[(RT_SHADE_REC_FLOATS / 4) * static_cast<size_t>(ref) + 1], n2 = S.shadeRecs[(RT_SHADE_REC_FLOATS / 4) * static_cast<size_t>(ref) + 2];
+                    float4 const n1 = S.shadeRecs[3 * static_cast<size_t>(ref) + 1], n2 = S.shadeRecs[3 * static_cast<size_t>(ref) + 2];
                     V3 const vn1 = mk(n0.y, n0.z, n0.w), vn2 = mk(n1.x, n1.y, n1.z), vn3 = mk(n1.w, n2.x, n2.y);
                     float const c2 = H.y, c3 = H.z;
                     float const c1 = 1.0f - c2 - c3;

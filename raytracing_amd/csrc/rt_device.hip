@@ -420,7 +420,7 @@ int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, ui
     // ---- triangle records and ids in the hierarchy's order -----------------------------------------------
     std::vector<float> tris(12 * static_cast<size_t>(std::max<uint32_t>(triCount, 1)), 0.0f);
     std::vector<uint32_t> ids(4 * static_cast<size_t>(std::max<uint32_t>(triCount, 1)), 0u);
-    std::vector<float> shadeRecs(RT_SHADE_REC_FLOATS * static_cast<size_t>(std::max<uint32_t>(triCount, 1)), 0.0f);
+    std::vector<float> shadeRecs(12 * static_cast<size_t>(std::max<uint32_t>(triCount, 1)), 0.0f);
     {
         if (D->model_count && (!D->model_vertex_begin || !D->model_tri_begin || (D->vertex_count && !D->vertex_normals)
                                || (D->base_tri_count && !D->base_tris)))
@@ -443,7 +443,7 @@ int attachBvh(rt_scene* s, const rt_scene_desc* D, const rt_bvh4_node* nodes, ui
             uint32_t const m = modelOf[g];
             uint32_t const rec[4] = {m, g - D->model_pretri_begin[m], g, 0u};
             std::memcpy(ids.data() + 4 * static_cast<size_t>(k), rec, 16);
-            rt_internal_shade_record(shadeRecs.data() + RT_SHADE_REC_FLOATS * static_cast<size_t>(k), m, triNormals.data() + 9 * static_cast<size_t>(g));
+            rt_internal_shade_record(shadeRecs.data() + 12 * static_cast<size_t>(k), m, triNormals.data() + 9 * static_cast<size_t>(g));
         }
     }
     // ---- upload ---------------------------------------------------------------------------------------------

@@ -427,9 +427,9 @@ int rt_internal_flatten(const rt_scene_desc* D, rt_flat_scene& F) {
         int const rc = rt_internal_gather_tri_normals(D, "rt_scene_create", triNormals);
         if (rc != RT_OK) return rc;
     }
-    F.shadeRecs.assign(RT_SHADE_REC_FLOATS * static_cast<size_t>(std::max<uint32_t>(refCount, 1)), 0.0f);
+    F.shadeRecs.assign(12 * static_cast<size_t>(std::max<uint32_t>(refCount, 1)), 0.0f);
     for (uint32_t r = 0; r < refCount; ++r)
-        rt_internal_shade_record(F.shadeRecs.data() + RT_SHADE_REC_FLOATS * static_cast<size_t>(r), F.leafIds[4 * static_cast<size_t>(r)],
+        rt_internal_shade_record(F.shadeRecs.data() + 12 * static_cast<size_t>(r), F.leafIds[4 * static_cast<size_t>(r)],
                                  triNormals.data() + 9 * static_cast<size_t>(F.leafIds[4 * static_cast<size_t>(r) + 2]));
     F.refCount = refCount;
     F.depth = maxDepth;

@@ -8,10 +8,6 @@
 #include <cstdint>
 #include <vector>
 
-// A shading record holds 12 floats and is stored with a stride of 16: one 64-byte line per record, so that the one
-// scattered fetch a shaded hit costs touches one line of memory, not one and a half on average.
-#define RT_SHADE_REC_FLOATS 16
-
 struct rt_flat_scene {
     // `packed` holds the leaf bounds records (64 bytes each, in the form leafAxes says, see rt_leaf_bounds.h), the record of
     // node slot s at byte 64 * (frontSlots - 1 - s), then the node records (32 bytes each).  The kernels' node pointer is
@@ -22,7 +18,7 @@ struct rt_flat_scene {
     uint32_t leafAxes = 1;              // RT_LEAF_AXES_ONE (cone form) or RT_LEAF_AXES_PACKED (axes form)
     std::vector<float> leafTris;        // 12 floats per (leaf, triangle) reference, plus one spare record
     std::vector<uint32_t> leafIds;      // {model, tri, scene-wide triangle, 0} per reference
-    std::vector<float> shadeRecs;       // RT_SHADE_REC_FLOATS per reference: {model, vn1} {vn2, vn3.x} {vn3.yz, 0, 0} and padding
+    std::vector<float> shadeRecs;       // 12 floats per reference: {model, vn1} {vn2, vn3.x} {vn3.yz, 0, 0}
     uint32_t refCount = 0, depth = 0;
     float rootLo[3] = {0, 0, 0}, rootHi[3] = {0, 0, 0};
     float boxAbsMax = 0.0f;             // largest |coordinate| of the root box
