@@ -270,12 +270,18 @@ int adoptStream(rt_scene* s, hipStream_t st) {
 }
 
 // No C++ exception may cross the C ABI: every entry point that can allocate runs its body through this.
+// (Building the message can itself run out of memory; then the status is returned with an empty message.)
+int failQuietly(int code, const char* what, const char* why) noexcept {
+    try { g_lastError.assign(what).append(": ").append(why); }
+    catch (...) { g_lastError.clear(); }
+    return code;
+}
 template <class Body>
-int guarded(const char* what, Body&& body) {
+int guarded(const char* what, Body&& body) noexcept {
     try { return body(); }
-    catch (std::bad_alloc const&) { return fail(RT_ERR_NOMEM, std::string(what) + ": out of host memory"); }
-    catch (std::exception const& e) { return fail(RT_ERR_INVALID, std::string(what) + ": " + e.what()); }
-    catch (...) { return fail(RT_ERR_INVALID, std::string(what) + ": unexpected exception"); }
+    catch (std::bad_alloc const&) { return failQuietly(RT_ERR_NOMEM, what, "out of host memory"); }
+    catch (std::exception const& e) { return failQuietly(RT_ERR_INVALID, what, e.what()); }
+    catch (...) { return failQuietly(RT_ERR_INVALID, what, "unexpected exception"); }
 }
 
 }  // namespace
@@ -727,8 +733,9 @@ int rt_scene_info(const rt_scene* s, uint64_t* device_bytes, uint32_t* node_coun
     return RT_OK;
 }
 
-int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_directions, uint64_t n, float t_min,
-                        int front_only, rt_hit* d_out, void* hip_stream) {
+namespace {
+int intersectDevice(rt_scene* s, const float* d_origins, const float* d_directions, uint64_t n, float t_min,
+                    int front_only, rt_hit* d_out, void* hip_stream) {
     if (!s || (n && (!d_origins || !d_directions || !d_out))) return fail(RT_ERR_INVALID, "rt_intersect: null argument");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
@@ -777,6 +784,12 @@ int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_dire
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
+}  // namespace
+
+int rt_intersect_device(rt_scene* s, const float* d_origins, const float* d_directions, uint64_t n, float t_min,
+                        int front_only, rt_hit* d_out, void* hip_stream) {
+    return guarded("rt_intersect_device", [&] { return intersectDevice(s, d_origins, d_directions, n, t_min, front_only, d_out, hip_stream); });
+}
 
 namespace {
 // Host-pointer form shared by rt_intersect and rt_intersect_check (stats != nullptr: the counting traversal of the BSP tree).
@@ -797,7 +810,7 @@ int intersectHost(rt_scene* s, const float* origins, const float* directions, ui
     if (e == hipSuccess) e = hipMemcpy(dO, origins, n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dD, directions, n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess && !stats) {
-        rc = rt_intersect_device(s, dO, dD, n, t_min, front_only, dH, nullptr);
+        rc = intersectDevice(s, dO, dD, n, t_min, front_only, dH, nullptr);
         if (rc == RT_OK) e = hipDeviceSynchronize();
     }
     else if (e == hipSuccess) {
@@ -1054,7 +1067,8 @@ int rt_render_multi_device(rt_scene* const* scenes, uint32_t scene_count, const 
     return guarded("rt_render_multi_device", [&] { return renderMulti(scenes, scene_count, p, d_out_rgb, nullptr, stats); });
 }
 
-int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* stats) {
+namespace {
+int renderHost(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* stats) {
     if (!s || !p || !out_rgb) return fail(RT_ERR_INVALID, "rt_render: null argument");
     HIP_TRY(hipSetDevice(s->device));
     uint64_t const pixels = static_cast<uint64_t>(p->w) * p->h;
@@ -1071,6 +1085,11 @@ int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* 
     if (rc != RT_OK) return rc;
     HIP_TRY(hipMemcpy(out_rgb, s->wsOut, pixels * 12, hipMemcpyDeviceToHost));
     return RT_OK;
+}
+}  // namespace
+
+int rt_render(rt_scene* s, const rt_render_params* p, float* out_rgb, rt_stats* stats) {
+    return guarded("rt_render", [&] { return renderHost(s, p, out_rgb, stats); });
 }
 
 #ifdef RT_DIAG
@@ -1089,6 +1108,7 @@ int rt_diag_read(unsigned long long* out16, int reset) {
 
 // Test hook: evaluates one scalar building block on the GPU for n inputs (see k_selftest).
 int rt_selftest_math(int op, const float* a, const float* b, uint32_t n, float* out) {
+  return guarded("rt_selftest_math", [&]() -> int {
     if (!a || !b || !out || n == 0) return fail(RT_ERR_INVALID, "rt_selftest_math: null argument");
     uint32_t const outPer = (op == 2 || op == 3) ? 2 : 1;
     float *dA = nullptr, *dB = nullptr, *dO = nullptr;
@@ -1107,6 +1127,7 @@ int rt_selftest_math(int op, const float* a, const float* b, uint32_t n, float* 
     if (dO) (void)hipFree(dO);
     if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_selftest_math: ") + hipGetErrorString(e));
     return RT_OK;
+  });
 }
 
 }  // extern "C"
