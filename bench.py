@@ -91,7 +91,8 @@ def cpu_baseline(scene, width, height, bounce_limit, target_seconds=12.0):
         dt = time.perf_counter() - t0
     finally:
         osc.close()
-    return {"value": st["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port-avx2",
+    return {"value": st["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "port_variant": "the reference's 8-triangle AVX2+FMA leaf test (src/geometry.hpp:117-132), OpenMP threads over pixels",
             "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
             "sample": f"full {width}x{height} frame at {spp} spp ({st['segments']} segments in {dt:.2f} s), "
                       f"8-triangle AVX2+FMA leaf test, {threads} threads over pixels",
