@@ -100,11 +100,14 @@ def test_leaf_bounds_rule_never_drops_a_leaf_that_yields_a_hit(c):
         assert wrong_fixed >= 100, "the fixture no longer holds the lines a fixed padding gets wrong"
 
 
-def test_leaf_bounds_rule_on_fresh_adversarial_scenes():
+@pytest.mark.parametrize("form", ["1", "3"])
+def test_leaf_bounds_rule_on_fresh_adversarial_scenes(form, monkeypatch):
     """tools/leaf_bounds_check.py on scenes and lines drawn now (a different seed every day would be no test; the seed is
-    fixed, the fixture's is another)."""
+    fixed, the fixture's is another), with the bounds records forced into the cone form (1) and into the three-axes form (3):
+    the library picks one form per scene, and rotated single triangles would always get the first."""
     from oracle import binding
     import leaf_bounds_check as lbc
+    monkeypatch.setenv("RT_AMD_LEAF_AXES", form)
     rng = np.random.default_rng(77)
     total = dict(wrong=0, wrong_fixed=0, hits=0)
     for k in range(4):
@@ -142,12 +145,14 @@ def test_gpu_grazing_lines_bit_exact(c):
 
 
 @pytest.mark.gpu
-def test_gpu_fresh_grazing_lines_against_oracle():
+@pytest.mark.parametrize("form", ["1", "3"])
+def test_gpu_fresh_grazing_lines_against_oracle(form, monkeypatch):
     """Many more lines than the fixture holds, drawn here, against the oracle on the same tree: hits equal, no
-    disagreement counted."""
+    disagreement counted; with the bounds records (and with them the kernels) of either form."""
     from oracle import binding
     from helpers import base_from_scene
     from raytracing_amd.render import DeviceScene, RayTraceData
+    monkeypatch.setenv("RT_AMD_LEAF_AXES", form)
     rng = np.random.default_rng(4242)
     for k, (scale, targets, cap, edges) in enumerate([(1.0, 1, 32, (1.0, 10.0)), (25.0, 8, 1, (0.02, 2.0)), (300.0, 1, 32, (3e-3, 0.3))]):
         scene, tris = grazing.make_scene(rng, scale, targets=targets, edge_range=edges)
