@@ -156,7 +156,10 @@ def roofline(workload, work, seg_per_launch, launch_ms, trace_share, accel="bsp"
            "box_tests_per_segment": work["box_tests"] / work["segments"],
            "tris_tested_per_segment": work["tris_tested"] / work["segments"],
            "node_visits_per_segment": work["inode_visits"] / work["segments"],
-           "shaded_hits_per_segment": work["shaded_hits"] / work["segments"]}
+           "shaded_hits_per_segment": work["shaded_hits"] / work["segments"],
+           # the counting step evaluates every conservative shortcut of the traversal beside the exact test: anything but 0 is a bug
+           "shortcut_disagreements_in_counting_step": work.get("box_filter_errors", 0),
+           "counting_step_segments": work["segments"]}
     # counter passes are per scene: the 4K workload shares the 1080p one's
     pmc_file = os.path.join(ROOT, "profiles", f"roofline_{ {'dragon4k': 'dragon'}.get(workload, workload) }{'_bvh' if accel == 'bvh' else ''}.json")
     traffic = None
