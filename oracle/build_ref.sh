@@ -34,6 +34,20 @@ g++ "${flags[@]}" -E -I"$ref/src" -I"$ref/libraries/glm" "$here/ref_harness.cpp"
   | g++ "${flags[@]}" -x c++-cpp-output - -shared -o "$out/libref.so"
 echo "built $out/libref.so"
 
+# The same harness with contraction allowed, as the author's MSVC /fp:fast build had it: only used to show where the
+# reference's own example_render.png got its darker floor from (tests/test_oracle_vs_ref.py); never a source of expected
+# values.
+fast=("${flags[@]/-ffp-contract=off/-ffp-contract=fast}")
+g++ "${fast[@]}" -E -I"$ref/src" -I"$ref/libraries/glm" "$here/ref_harness.cpp" \
+  | sed -e 's/typedef IndexType IndexType;//' \
+        -e 's/typedef SizeType SizeType;//' \
+        -e 's/\(VertexRange\|TriRange\)::\(IndexType\|SizeType\)/std::uint32_t/g' \
+        -e 's/data\.m128_f32\[/((float*)\&data)[/g' \
+        -e 's/data\.m256_f32\[/((float*)\&data)[/g' \
+        -e 's/data\.m256i_u32\[/((std::uint32_t*)\&data)[/g' \
+  | g++ "${fast[@]}" -x c++-cpp-output - -shared -o "$out/libref_contracted.so"
+echo "built $out/libref_contracted.so"
+
 # The reference program with render() bound to librt_amd.so (oracle/ref_dropin.cpp): same recipe, linked
 # against the product library, which it finds next to the repository's package at run time.
 lib="$here/../raytracing_amd"

@@ -88,3 +88,36 @@ def test_postprocess_stages(oracle_lib, ref_lib):
         ma, mb = oracle_lib.median3(a), ref_lib.median3(a)
         assert np.array_equal(ma[1:-1, 1:-1], mb[1:-1, 1:-1])
         assert np.array_equal(oracle_lib.to_u8(ma), ref_lib.to_u8(ma))
+
+
+def test_example_render_floor_comes_from_contraction(oracle_lib, ref_lib):
+    """Where the reference's own picture (example_render.png, fixture example_render_480x270.npz) differs from a faithful
+    evaluation of its source text.  The compiled reference renders its built-in scene twice, built without floating-point
+    contraction (the build the oracle is pinned to) and with it (as the author's MSVC /fp:fast build had it;
+    oracle/_ref/libref_contracted.so).  Cubes, mirrors and background agree with the picture either way; the floor -- which
+    lies exactly on the root box's lower face, where the leaf's in-box rule (src/bsp.hpp:80-84) depends on how
+    origin + t * direction is rounded -- matches the picture only with contraction, and is brighter without."""
+    import os
+    from helpers import golden
+    from oracle import binding
+    path = os.path.join(os.path.dirname(binding.REF_SO), "libref_contracted.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_contracted.so not built")
+    g = golden("example_render_480x270.npz")
+    picture = g["image"].astype(np.float64)
+    lum = picture.mean(axis=2)
+    bright, dark = lum >= 80, lum < 10
+    floor = ~bright & ~dark
+    result = {}
+    for name, lib in (("plain", ref_lib), ("contracted", binding._Lib(path, "ref"))):
+        s = lib.scene_builtin(3, 480, 270)
+        try:
+            hdr = s.render(128, 4711)
+        finally:
+            s.close()
+        result[name] = oracle_lib.postprocess(hdr).astype(np.float64) - picture
+    for name, diff in result.items():
+        assert abs(diff[bright].mean()) < 1.5, (name, diff[bright].mean())
+        assert abs(diff[dark].mean()) < 1.5, (name, diff[dark].mean())
+    assert abs(result["contracted"][floor].mean()) < 3.0, result["contracted"][floor].mean()
+    assert 5.0 < result["plain"][floor].mean() < 14.0, result["plain"][floor].mean()
