@@ -263,8 +263,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     comm_device = "cpu" if share_gpu else "cuda"
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: go through the multi-rank code (process group, scene broadcast, band gather, reductions) even
+    # with one rank, so that the RCCL path can be executed on a box with a single GPU.
+    distributed = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")          # only used when not started by torch.distributed.run
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -286,12 +290,13 @@ def main():
         rtd = RayTraceData(scene)
         header = np.concatenate([scene.camera.position, scene.pixel_to_ray_transform(width, height),
                                  [len(scene.preprocessed_tris.tris)]]).astype(np.float64)
-    if world > 1:
+    if distributed:
         blob = tiles.broadcast_bytes(serialize_scene(rtd) if rank == 0 else None, rank, dist, comm_device)
         head = torch.from_numpy(header).to(comm_device) if rank == 0 else torch.zeros(13, dtype=torch.float64, device=comm_device)
         dist.broadcast(head, src=0)
         header = head.cpu().numpy()
-        ds = DeviceScene(rtd, device=local_rank) if rank == 0 else DeviceScene.from_blob(blob, device=local_rank)
+        # rank 0 keeps its own description; every other rank (and rank 0 of a forced single-rank run) uploads from the bytes
+        ds = DeviceScene(rtd, device=local_rank) if rank == 0 and world > 1 else DeviceScene.from_blob(blob, device=local_rank)
         scene_bytes = int(blob.size)
         del blob
     else:
@@ -309,10 +314,11 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     # One rectangle per GPU when alone; otherwise 8 bands per rank, dealt round-robin and rendered by one call
     # per frame (tools/band_balance.py: max/mean rank load 1.03 at 8 ranks on the 0.9M-triangle scene, 1.07 with 4).
-    bands_per_rank = 1 if world == 1 else 8
+    bands_per_rank = 8 if distributed else 1
     render_buf = torch.zeros(tiles.max_rank_rows(height, world, bands_per_rank) * width * 3, dtype=torch.float32, device="cuda")
     gatherer = tiles.FrameGatherer(width, height, rank, world, bands_per_rank, dist,
-                                   buffer=(torch.zeros(render_buf.numel()) if share_gpu and world > 1 else render_buf))
+                                   buffer=(torch.zeros(render_buf.numel()) if share_gpu and world > 1 else render_buf),
+                                   always_gather=distributed)
     extra = ((_lib.RT_FLAG_RUSSIAN_ROULETTE if args.roulette else 0) | (_lib.RT_FLAG_ACCEL_BVH if args.accel == "bvh" else 0)
              | (_lib.RT_FLAG_LOBE_SAMPLING if args.lobes else 0) | (_lib.RT_FLAG_SORT_RAYS if args.sort else 0))
 
@@ -329,7 +335,7 @@ def main():
         return st, gatherer.gather()
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -352,7 +358,7 @@ def main():
     dt = time.perf_counter() - t0
 
     seg_rank = seg
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt, float(seg)], dtype=torch.float64, device=comm_device)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -371,7 +377,7 @@ def main():
                        "accelerator": "reference BSP tree" if args.accel == "bsp" else "4-wide bounding volume hierarchy (not the reference's accelerator)",
                        "bvh_build_s": bvh_build_s,
                        "parallelism": (f"pixel bands over {world} GPUs, scene broadcast once from rank 0 "
-                                       f"({scene_bytes / 1e6:.1f} MB), bands gathered to rank 0 every frame") if world > 1
+                                       f"({scene_bytes / 1e6:.1f} MB), bands gathered to rank 0 every frame") if distributed
                        else "one GPU, one rectangle",
                        "scene_setup_s": setup_s, "segments_per_step": seg / args.steps, "image_finite": finite},
             "roofline": roofline(args.workload, work, seg_rank / max(launches, 1), trace_ms / max(launches, 1),
@@ -407,7 +413,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(scene, width, height, bounce_limit)
         print(json.dumps(line), flush=True)
     ds.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

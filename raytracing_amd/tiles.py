@@ -73,19 +73,21 @@ class FrameGatherer:
     RCCL point-to-point transfers over xGMI with the "nccl" backend, gloo on CPU), which puts them back into
     frame order.  All buffers are allocated once, here."""
 
-    def __init__(self, width, height, rank, world_size, bands_per_rank=4, dist=None, device=None, buffer=None):
+    def __init__(self, width, height, rank, world_size, bands_per_rank=4, dist=None, device=None, buffer=None,
+                 always_gather=False):
         import torch
         self.width, self.height, self.rank, self.world, self.bpr, self.dist = width, height, rank, world_size, bands_per_rank, dist
+        self.collective = world_size > 1 or always_gather       # always_gather: a single rank goes through the collective too
         per = max_rank_rows(height, world_size, bands_per_rank) * width * 3
         self.buffer = buffer if buffer is not None else torch.zeros(per, dtype=torch.float32, device=device)
         assert self.buffer.numel() >= per
         self.parts = self.frame = None
-        if world_size > 1 and rank == 0:
+        if self.collective and rank == 0:
             self.parts = [torch.empty_like(self.buffer) for _ in range(world_size)]
             self.frame = torch.empty(height, width, 3, dtype=self.buffer.dtype, device=self.buffer.device)
 
     def gather(self):
-        if self.world == 1:
+        if not self.collective:
             return self.buffer[: self.height * self.width * 3].view(self.height, self.width, 3)
         self.dist.gather(self.buffer, self.parts if self.rank == 0 else None, dst=0)
         if self.rank != 0:

@@ -852,6 +852,34 @@ def test_bench_two_rank_rehearsal_on_one_gpu(accel):
     assert out["config"]["segments_per_step"] > 640 * 480 * 4
 
 
+def test_bench_multi_rank_code_over_rccl_with_one_rank():
+    """The same multi-rank code with the transport the 2/4/8-GPU runs use: a one-rank process group on the "nccl" backend
+    (RCCL), RT_BENCH_FORCE_DIST=1 -- scene bytes broadcast as a device tensor, scene uploaded from the bytes, bands of the
+    frame gathered through the collective, timing reduced over the group.  One GPU cannot show scaling; it can show that
+    every collective call of that path executes on RCCL with the tensors bench.py hands it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.pop("RT_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--spp", "4",
+           "--workload", "builtin", "--no-alt", "--no-cpu-baseline"]
+    run = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["image_finite"] is True
+    assert "broadcast once" in out["config"]["parallelism"]
+    assert out["config"]["segments_per_step"] > 640 * 480 * 4
+
+
 @pytest.mark.parametrize("scale,offset", [(1.0, (0, 0, 0)), (1e-3, (0, 0, 0)), (0.05, (0, 0, 0)), (3e3, (0, 0, 0)),
                                           (1.0, (500, -200, 1000)), (0.02, (7, 7, 7))])
 def test_random_soups_at_many_scales_bit_exact(oracle_lib, scale, offset):
