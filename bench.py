@@ -89,9 +89,17 @@ def cpu_baseline(scene, width, height, bounce_limit, target_seconds=12.0):
         t0 = time.perf_counter()
         _, st = osc.render_device_mode(osc.render_params(spp, bounce_limit=bounce_limit, seed=99), threads=threads)
         dt = time.perf_counter() - t0
+        # One thread, a quarter of the rows at 1 spp: the rate of the reference as g++ builds it where TBB is absent (its
+        # std::execution::par then runs serially, src/render.hpp:218), for the record beside the threaded number.
+        rect = (0, height // 2 - height // 8, width, max(1, height // 4))
+        t0 = time.perf_counter()
+        _, st1 = osc.render_device_mode(osc.render_params(1, bounce_limit=bounce_limit, seed=98, rect=rect), threads=1)
+        dt1 = time.perf_counter() - t0
     finally:
         osc.close()
     return {"value": st["segments"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": st1["segments"] / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                              "sample": f"rows {rect[1]}..{rect[1] + rect[3] - 1} at 1 spp ({st1['segments']} segments in {dt1:.2f} s)"},
             "port_variant": "the reference's 8-triangle AVX2+FMA leaf test (src/geometry.hpp:117-132), OpenMP threads over pixels",
             "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
             "sample": f"full {width}x{height} frame at {spp} spp ({st['segments']} segments in {dt:.2f} s), "
