@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""CPU check of the conservative ray/box filter used in front of the exact six-face test.
+"""TEST INFRASTRUCTURE (a checker: it compares the library with the oracle; the library never uses it).
+CPU check of the conservative ray/box filter used in front of the exact six-face test.
 
 For many (line, box) pairs, including lines aimed a few ulps around box corners, edges and faces, the
 filter's "surely meets" / "surely misses" decisions are compared with the exact test (the oracle's

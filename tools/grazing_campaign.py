@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A larger run of what tests/test_grazing.py does with fixed seeds: many fresh adversarial scenes (rotated triangles of
+"""TEST INFRASTRUCTURE (a checker: it compares the library with the oracle; the library never uses it).
+A larger run of what tests/test_grazing.py does with fixed seeds: many fresh adversarial scenes (rotated triangles of
 every size and shape, alone in their leaves or sharing them; scenes from millimetres to kilometres) and lines that graze
 the triangles' planes a little outside the triangles, traced on the GPU by rt_intersect and by rt_intersect_check (the
 kernels that cross-check every conservative shortcut against the exact evaluation) and compared with the oracle's

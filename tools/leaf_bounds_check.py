@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""CPU check of the rule by which the traversal leaves a BSP leaf unscanned (rtLeafBoundsMiss, rt_leaf_bounds.h).
+"""TEST INFRASTRUCTURE (a checker: it compares the library with the oracle; the library never uses it).
+CPU check of the rule by which the traversal leaves a BSP leaf unscanned (rtLeafBoundsMiss, rt_leaf_bounds.h).
 
 For adversarial scenes and lines (tests/grazing.py: lines that graze the planes of rotated triangles of every size, in
 scenes from millimetres to kilometres) every (line, leaf) pair is evaluated twice: the oracle's restatement of the
